@@ -1,0 +1,118 @@
+// gpmc_common.h -- shared device/host helpers for libgpmc (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gpmc.h"
+
+namespace gpmc {
+
+// ---------------------------------------------------------------- error plumbing
+extern thread_local char g_err[512];
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define GPMC_HIP(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return gpmc::fail((int)e__, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+    } while (0)
+#define GPMC_ARG(cond, k)                                                                         \
+    do {                                                                                          \
+        if (!(cond)) return gpmc::fail(-(k), "%s: bad argument %d: !(%s)", __func__, (k), #cond); \
+    } while (0)
+#define GPMC_LAUNCH_CHECK() GPMC_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- options
+struct Options {
+    int outer_nb = 256;   // outer block of the right-looking Cholesky (multiple of 128)
+    int lookahead = 1;    // factor panel k+1 on a second stream while the trailing update of k runs
+    int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
+    int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
+};
+extern Options g_opt;
+
+// ---------------------------------------------------------------- vector / MFMA traits
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+
+// v_mfma_f64_16x16x4_f64: A[row=l&15][k=l>>4], B[k=l>>4][col=l&15], D: col=l&15, row=(l>>4)+4*reg.
+template <>
+struct Mfma<double> {
+    typedef d4_t acc_t;
+    typedef d2_t frag_t;                 // one 16-byte LDS read = 2 k-values
+    static constexpr int EPL = 2;        // elements per 16-byte lane read
+    __device__ static inline acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // row of accumulator register e for lane-quarter q
+    __device__ static inline int crow(int q, int e) { return q + 4 * e; }
+};
+// v_mfma_f32_16x16x4_f32: same A/B maps, D: col=l&15, row=4*(l>>4)+reg.
+template <>
+struct Mfma<float> {
+    typedef f4_t acc_t;
+    typedef f4_t frag_t;                 // 4 k-values per 16-byte read
+    static constexpr int EPL = 4;
+    __device__ static inline acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline int crow(int q, int e) { return 4 * q + e; }
+};
+
+template <typename T>
+__device__ inline typename Mfma<T>::acc_t acc_zero() {
+    typename Mfma<T>::acc_t z;
+    z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0;
+    return z;
+}
+
+constexpr int NB_IN = 64;  // inner (diagonal-block) size of the Cholesky
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------- internal entry points
+template <typename T>
+int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
+           int rows_out, int cols_out, int ldk, int flags, hipStream_t s);
+template <typename T>
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s);
+template <typename T>
+int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s);
+template <typename T>
+int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s);
+template <typename T>
+int pack_rows(const T* B, int nrhs, int n, int ldb, T* W, int mp, int np_, int ldw, hipStream_t s);
+template <typename T>
+int unpack_lower(const T* W, int np_, int ldw, T* L, int n, int ldl, hipStream_t s);
+template <typename T>
+int unpack_rows(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, hipStream_t s);
+template <typename T>
+int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_, int ldc,
+              hipStream_t s);
+template <typename T>
+int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s);
+template <typename T>
+int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStream_t s);
+
+// look-ahead resources (second stream + events), created lazily per process
+struct Aux {
+    hipStream_t panel_stream = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ready = false;
+};
+int aux_get(Aux** out);
+
+}  // namespace gpmc

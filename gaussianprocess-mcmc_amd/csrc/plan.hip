@@ -1,0 +1,271 @@
+// plan.hip -- fused log-marginal plan + the extern "C" surface of libgpmc.so.
+//
+// One plan = one (kernel, n, d, dtype) problem bound to caller-owned device memory.  An evaluation is
+//   H2D(16..80 B of kernel parameters) -> [ kbuild(lower, S on the diagonal, identity padding)
+//   -> copy g into the riding row -> blocked Cholesky -> log-det / quadratic-form reduction ] -> D2H(32 B)
+// The bracketed part is a static launch sequence (~400 launches at N=8192, two streams for the
+// look-ahead); it is captured once into a hipGraph and replayed, so the host cost per evaluation is
+// one graph launch instead of hundreds of kernel launches.
+#include <cmath>
+#include <new>
+
+#include "gpmc_common.h"
+
+namespace gpmc {
+
+constexpr int PLAN_SLOTS = 64;
+constexpr int PLAN_MAXD = 62;
+
+struct PlanLayout {
+    int np_, mp, ld;
+    size_t off_W, off_X, off_g, off_hyp, off_out, off_info, off_scratch, total;
+};
+
+static PlanLayout plan_layout(int n, int d, int es) {
+    PlanLayout L;
+    L.np_ = round_up(n, GPMC_PAD);
+    L.mp = L.np_ + GPMC_PAD;
+    L.ld = L.np_;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    L.off_W = take((size_t)L.mp * L.ld * es);
+    L.off_X = take((size_t)n * d * es);
+    L.off_g = take((size_t)n * es);
+    L.off_hyp = take((size_t)(2 + PLAN_MAXD) * es);
+    L.off_out = take(4 * sizeof(double));
+    L.off_info = take(sizeof(int));
+    L.off_scratch = take((size_t)(L.np_ / NB_IN) * 1024 * es);
+    L.total = o;
+    return L;
+}
+
+}  // namespace gpmc
+
+struct gpmc_plan {
+    int kernel, n, d, es;
+    gpmc::PlanLayout L;
+    char* ws;
+    hipStream_t stream;
+    double* host_pin;     // PLAN_SLOTS x (2+MAXD) staged parameters (as T bytes) + PLAN_SLOTS x 4 results
+    size_t hyp_slot_bytes;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int evals;
+    bool have_data;
+};
+
+namespace gpmc {
+
+template <typename T>
+static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
+    const PlanLayout& L = p->L;
+    T* W = reinterpret_cast<T*>(p->ws + L.off_W);
+    const T* X = reinterpret_cast<const T*>(p->ws + L.off_X);
+    const T* g = reinterpret_cast<const T*>(p->ws + L.off_g);
+    const T* hyp = reinterpret_cast<const T*>(p->ws + L.off_hyp);
+    double* out = reinterpret_cast<double*>(p->ws + L.off_out);
+    int* info = reinterpret_cast<int*>(p->ws + L.off_info);
+    int rc = kbuild<T>(p->kernel, X, p->n, p->d, p->d, nullptr, 0, 0, hyp, W, L.np_, L.np_, L.ld,
+                       GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s);
+    if (rc) return rc;
+    GPMC_HIP(hipMemcpyAsync(W + (size_t)L.np_ * L.ld, g, (size_t)p->n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s);
+    if (rc) return rc;
+    return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s);
+}
+
+static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
+    return p->es == 8 ? plan_enqueue_body<double>(p, s) : plan_enqueue_body<float>(p, s);
+}
+
+}  // namespace gpmc
+
+using namespace gpmc;
+
+extern "C" {
+
+int gpmc_version(void) { return GPMC_VERSION; }
+const char* gpmc_last_error(void) { return g_err; }
+int gpmc_pad(int n) { return round_up(n, GPMC_PAD); }
+size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double); }
+
+int gpmc_set_option(const char* name, int value) {
+    if (!name) return fail(-1, "gpmc_set_option: null name");
+    if (!strcmp(name, "outer_nb")) { if (value < 128 || value % 128) return fail(-2, "outer_nb must be a multiple of 128"); g_opt.outer_nb = value; }
+    else if (!strcmp(name, "lookahead")) g_opt.lookahead = value ? 1 : 0;
+    else if (!strcmp(name, "use_graph")) g_opt.use_graph = value ? 1 : 0;
+    else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
+    else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
+    return 0;
+}
+int gpmc_get_option(const char* name) {
+    if (!name) return -1;
+    if (!strcmp(name, "outer_nb")) return g_opt.outer_nb;
+    if (!strcmp(name, "lookahead")) return g_opt.lookahead;
+    if (!strcmp(name, "use_graph")) return g_opt.use_graph;
+    if (!strcmp(name, "small_tile_m")) return g_opt.small_tile_m;
+    return -1;
+}
+
+#define S_(x) reinterpret_cast<hipStream_t>(x)
+
+int gpmc_kbuild_f64(int kernel, const double* X, int n, int d, int ldx, const double* Z, int nz, int ldz,
+                    const double* hyp_dev, double* K, int rows_out, int cols_out, int ldk, int flags,
+                    gpmc_stream_t stream) {
+    return kbuild<double>(kernel, X, n, d, ldx, Z, nz, ldz, hyp_dev, K, rows_out, cols_out, ldk, flags, S_(stream));
+}
+int gpmc_kbuild_f32(int kernel, const float* X, int n, int d, int ldx, const float* Z, int nz, int ldz,
+                    const float* hyp_dev, float* K, int rows_out, int cols_out, int ldk, int flags,
+                    gpmc_stream_t stream) {
+    return kbuild<float>(kernel, X, n, d, ldx, Z, nz, ldz, hyp_dev, K, rows_out, cols_out, ldk, flags, S_(stream));
+}
+int gpmc_potrf_f64(double* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<double>(W, mp, np_, ldw, info_dev, scratch, S_(stream));
+}
+int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<float>(W, mp, np_, ldw, info_dev, scratch, S_(stream));
+}
+int gpmc_logdet_quad_f64(const double* W, int n, int ldw, const double* alpha_dev, const int* info_dev,
+                         double* out_dev, gpmc_stream_t stream) {
+    return logdet_quad<double>(W, n, ldw, alpha_dev, info_dev, out_dev, S_(stream));
+}
+int gpmc_logdet_quad_f32(const float* W, int n, int ldw, const float* alpha_dev, const int* info_dev,
+                         double* out_dev, gpmc_stream_t stream) {
+    return logdet_quad<float>(W, n, ldw, alpha_dev, info_dev, out_dev, S_(stream));
+}
+#define PACK_API(SFX, T)                                                                                          \
+    int gpmc_pack_lower_##SFX(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, gpmc_stream_t st) {   \
+        return pack_lower<T>(A, n, lda, jitter, W, np_, ldw, S_(st));                                             \
+    }                                                                                                             \
+    int gpmc_pack_rows_##SFX(const T* B, int nrhs, int n, int ldb, T* W, int mp, int np_, int ldw,                \
+                             gpmc_stream_t st) {                                                                  \
+        return pack_rows<T>(B, nrhs, n, ldb, W, mp, np_, ldw, S_(st));                                            \
+    }                                                                                                             \
+    int gpmc_unpack_lower_##SFX(const T* W, int np_, int ldw, T* L, int n, int ldl, gpmc_stream_t st) {           \
+        return unpack_lower<T>(W, np_, ldw, L, n, ldl, S_(st));                                                   \
+    }                                                                                                             \
+    int gpmc_unpack_rows_##SFX(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, gpmc_stream_t st) {  \
+        return unpack_rows<T>(W, np_, ldw, B, nrhs, n, ldb, S_(st));                                              \
+    }                                                                                                             \
+    int gpmc_syrk_diff_##SFX(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_,  \
+                             int ldc, gpmc_stream_t st) {                                                         \
+        return syrk_diff<T>(D, ldd, P, kp, ldp, diag_add, C, n, np_, ldc, S_(st));                                \
+    }                                                                                                             \
+    int gpmc_symv_lower_##SFX(const T* W, int n, int ldw, const T* x, T* y, gpmc_stream_t st) {                   \
+        return symv_lower<T>(W, n, ldw, x, y, S_(st));                                                            \
+    }                                                                                                             \
+    int gpmc_trmv_lower_##SFX(const T* W, int n, int ldw, const T* x, const T* y0, T* y, gpmc_stream_t st) {      \
+        return trmv_lower<T>(W, n, ldw, x, y0, y, S_(st));                                                        \
+    }
+PACK_API(f64, double)
+PACK_API(f32, float)
+
+// ------------------------------------------------------------------------------------- plan
+size_t gpmc_plan_workspace_bytes(int n, int d, int elem_size) {
+    if (n <= 0 || d <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
+    return plan_layout(n, d, elem_size).total;
+}
+
+int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, void* workspace,
+                     size_t workspace_bytes, gpmc_stream_t stream) {
+    GPMC_ARG(out != nullptr, 1);
+    GPMC_ARG(kernel == GPMC_KERNEL_RBF || kernel == GPMC_KERNEL_MATERN52_ARD, 2);
+    GPMC_ARG(n > 0, 3);
+    GPMC_ARG(d > 0 && d <= PLAN_MAXD, 4);
+    GPMC_ARG(elem_size == 4 || elem_size == 8, 5);
+    GPMC_ARG(workspace != nullptr && reinterpret_cast<uintptr_t>(workspace) % 256 == 0, 6);
+    PlanLayout L = plan_layout(n, d, elem_size);
+    GPMC_ARG(workspace_bytes >= L.total, 7);
+    gpmc_plan* p = new (std::nothrow) gpmc_plan();
+    if (!p) return fail(-1, "gpmc_plan_create: out of host memory");
+    p->kernel = kernel; p->n = n; p->d = d; p->es = elem_size; p->L = L;
+    p->ws = reinterpret_cast<char*>(workspace);
+    p->stream = S_(stream);
+    p->graph = nullptr; p->exec = nullptr; p->evals = 0; p->have_data = false;
+    p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD) * sizeof(double);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p->host_pin),
+                                 PLAN_SLOTS * (p->hyp_slot_bytes + 4 * sizeof(double)), hipHostMallocDefault);
+    if (e != hipSuccess) { delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    // zero the riding rows once: only row np_ is ever rewritten (with g), the others stay zero
+    e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
+                       (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
+    if (e != hipSuccess) { hipHostFree(p->host_pin); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+
+int gpmc_plan_set_data(gpmc_plan* p, const void* X_dev, int ldx, const void* g_dev) {
+    GPMC_ARG(p != nullptr, 1);
+    GPMC_ARG(X_dev != nullptr && ldx >= p->d, 2);
+    GPMC_ARG(g_dev != nullptr, 4);
+    GPMC_HIP(hipMemcpy2DAsync(p->ws + p->L.off_X, (size_t)p->d * p->es, X_dev, (size_t)ldx * p->es,
+                              (size_t)p->d * p->es, p->n, hipMemcpyDeviceToDevice, p->stream));
+    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_g, g_dev, (size_t)p->n * p->es, hipMemcpyDeviceToDevice, p->stream));
+    p->have_data = true;
+    return 0;
+}
+
+int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int slot) {
+    GPMC_ARG(p != nullptr && p->have_data, 1);
+    const int need = 2 + (p->kernel == GPMC_KERNEL_RBF ? 1 : p->d);
+    GPMC_ARG(kparams_host != nullptr && nk == need, 3);
+    GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 4);
+    char* hslot = reinterpret_cast<char*>(p->host_pin) + (size_t)slot * p->hyp_slot_bytes;
+    if (p->es == 8) {
+        memcpy(hslot, kparams_host, (size_t)nk * sizeof(double));
+    } else {
+        float* f = reinterpret_cast<float*>(hslot);
+        for (int i = 0; i < nk; ++i) f[i] = (float)kparams_host[i];
+    }
+    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)nk * p->es, hipMemcpyHostToDevice, p->stream));
+    int rc = 0;
+    if (!g_opt.use_graph || p->evals == 0) {
+        rc = plan_enqueue(p, p->stream);  // first evaluation runs eagerly (creates streams, sets attributes)
+    } else {
+        if (!p->exec) {
+            GPMC_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+            rc = plan_enqueue(p, p->stream);
+            hipError_t e = hipStreamEndCapture(p->stream, &p->graph);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            GPMC_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+        }
+        GPMC_HIP(hipGraphLaunch(p->exec, p->stream));
+    }
+    if (rc) return rc;
+    p->evals++;
+    double* hres = reinterpret_cast<double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
+    GPMC_HIP(hipMemcpyAsync(hres, p->ws + p->L.off_out, 4 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    return 0;
+}
+
+int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host) {
+    GPMC_ARG(p != nullptr, 1);
+    GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 2);
+    GPMC_ARG(out_host != nullptr, 3);
+    GPMC_HIP(hipStreamSynchronize(p->stream));
+    const double* hres = reinterpret_cast<const double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
+    for (int i = 0; i < 4; ++i) out_host[i] = hres[i];
+    return 0;
+}
+
+int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld) {
+    GPMC_ARG(p != nullptr, 1);
+    if (W) *W = p->ws + p->L.off_W;
+    if (mp) *mp = p->L.mp;
+    if (np_) *np_ = p->L.np_;
+    if (ld) *ld = p->L.ld;
+    return 0;
+}
+
+int gpmc_plan_destroy(gpmc_plan* p) {
+    if (!p) return 0;
+    hipStreamSynchronize(p->stream);
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    if (p->host_pin) hipHostFree(p->host_pin);
+    delete p;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// potrf.hip -- blocked right-looking Cholesky on MFMA.
+//
+// Replaces kcGP.tools.jitchol (kcMCMC/sliceSample.py:196,205: LAPACK dpotrf) and, through extra rows
+// riding below the matrix, np.linalg.solve(L, .) (sliceSample.py:108,197): factoring the leading np_
+// columns of the (mp x np_) lower trapezoid [A; B^T] leaves L in the triangle and B^T L^-T = (L^-1 B)^T
+// in the extra rows, so the forward substitution of the log-marginal (alpha = L^-1 g) and the N-RHS
+// solve V = L^-1 K cost no extra kernels.
+//
+// Structure (row-major, lower):
+//   outer block NB (256): right-looking;  trailing update C -= P P^T on v_mfma_f64_16x16x4_f64,
+//                         128x128 tiles, K = NB  (the MFMA-bound kernel of the metric)
+//   inner block 64:       left-looking inside the outer panel:
+//        panel_update (MFMA GEMM, 64x64 tiles, K = 64*j)
+//        diag_factor  (one workgroup, 64x64 block in LDS, one barrier per column, + the inverses of
+//                      its four 16x16 diagonal tiles)
+//        trsm_strip   (per wave 16 rows: X^T = L^-1 B^T by 16-blocks, a pure MFMA chain -- the f64
+//                      accumulator layout is exactly the B-operand layout, so no data movement)
+// With look-ahead the panel of step k+1 is factored on a second stream while the rest of the
+// trailing update of step k runs.
+#include "gpmc_common.h"
+
+namespace gpmc {
+
+Options g_opt;
+thread_local char g_err[512] = {0};
+
+static Aux g_aux;
+int aux_get(Aux** out) {
+    if (!g_aux.ready) {
+        int lo = 0, hi = 0;
+        GPMC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        GPMC_HIP(hipStreamCreateWithPriority(&g_aux.panel_stream, hipStreamNonBlocking, hi));
+        for (auto& e : g_aux.ev) GPMC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g_aux.ready = true;
+    }
+    *out = &g_aux;
+    return 0;
+}
+
+// ======================================================================= diagonal block
+// Factor the 64x64 block at Wd (lower triangle read) in LDS and write L back (strict upper = 0).
+// Column step c applies a[i][j] -= a[i][c] a[j][c] / d_c directly from the unscaled column, so only
+// one barrier per column is needed; columns are scaled by 1/sqrt(d_c) at the end (dpotf2 scales by
+// the reciprocal as well).  Also emits inv(L_tt) for the four 16x16 diagonal tiles (for trsm_strip).
+constexpr int DG_LD = NB_IN + 1;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+diag_factor_kernel(T* __restrict__ Wd, int ld, T* __restrict__ dinv, int* __restrict__ info, int c0) {
+    __shared__ T S[NB_IN][DG_LD];
+    __shared__ T sd[NB_IN], sdi[NB_IN];
+    __shared__ int sfail;
+    const int tid = threadIdx.x;
+    if (tid == 0) sfail = 0;
+    for (int e = tid; e < NB_IN * NB_IN; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        S[i][j] = (j <= i) ? Wd[(size_t)i * ld + j] : (T)0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int c = 0; c < NB_IN; ++c) {
+        const T dc = S[c][c];
+        if (tid == 0 && !(dc > (T)0) && sfail == 0) sfail = c0 + c + 1;
+        const T inv = (T)1 / dc;
+        for (int i = c + 1 + ty; i < NB_IN; i += 16) {
+            const T lic = S[i][c] * inv;
+            for (int j = c + 1 + tx; j <= i; j += 16) S[i][j] -= lic * S[j][c];
+        }
+        __syncthreads();
+    }
+    if (tid < NB_IN) {
+        const T s = sqrt(S[tid][tid]);
+        sd[tid] = s;
+        sdi[tid] = (T)1 / s;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB_IN * NB_IN; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        T v = (T)0;
+        if (j < i) v = S[i][j] * sdi[j];
+        else if (j == i) v = sd[i];
+        S[i][j] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB_IN * NB_IN; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        Wd[(size_t)i * ld + j] = S[i][j];
+    }
+    if (tid < NB_IN) {  // inverse of diagonal tile t, column jj, by forward substitution
+        const int t = tid >> 4, jj = tid & 15, o = 16 * t;
+        T x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            T s = (i == jj) ? (T)1 : (T)0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= S[o + i][o + k] * x[k];
+            x[i] = s * sdi[o + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dinv[t * 256 + i * 16 + jj] = x[i];
+    }
+    if (tid == 0 && sfail != 0) atomicCAS(info, 0, sfail);
+}
+
+// ======================================================================= TRSM strip
+// Rows r0.. (64 per workgroup, 16 per wave) of the panel: X = B L^-T, computed transposed,
+// Y = X^T (64 x 16 per wave) by 16-row blocks:  Y_jb = inv(L_jb,jb) (B^T_jb - sum_{p<jb} L_jb,p Y_p).
+// An accumulator tile is used as the next MFMA's B operand unchanged (register s <-> k-step s).
+constexpr int TS_LD = NB_IN + 2;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+trsm_strip_kernel(T* __restrict__ Wp, int ld, const T* __restrict__ Ld, const T* __restrict__ dinv) {
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    __shared__ T Ls[NB_IN][TS_LD];
+    __shared__ T Di[4][16][16 + 2];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB_IN * NB_IN; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        Ls[i][j] = Ld[(size_t)i * ld + j];
+    }
+    for (int e = tid; e < 4 * 256; e += 256) Di[e >> 8][(e >> 4) & 15][e & 15] = dinv[e];
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    T* rowp = Wp + ((size_t)blockIdx.x * 64 + wv * 16 + r) * ld;  // this lane's matrix row
+
+    acc_t Y[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        acc_t acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = rowp[16 * jb + M::crow(q, e)];
+#pragma unroll
+        for (int p = 0; p < jb; ++p) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const T a = -Ls[16 * jb + r][16 * p + M::crow(q, s)];
+                acc = M::mma(a, Y[p][s], acc);
+            }
+        }
+        acc_t out = acc_zero<T>();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const T a = Di[jb][r][M::crow(q, s)];
+            out = M::mma(a, acc[s], out);
+        }
+        Y[jb] = out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowp[16 * jb + M::crow(q, e)] = out[e];
+    }
+}
+
+// ======================================================================= GEMM / SYRK  (NT form)
+//   C[i][j] = (beta ? Cin[i][j] : 0) + alpha * sum_k A[i][k] B[j][k]        row-major, k contiguous
+// Tiles BM x BN = (WGM*TM*16) x (WGN*TN*16), 256 threads, K in steps of 128 bytes per row.
+// tri != 0: only tiles with tj <= ti are launched (BM == BN), rows beyond the ntc-th tile row form a
+// full rectangle (the riding right-hand sides).  EPI: add diag_add on the global diagonal and write
+// identity where the global row index >= n_true (gpmc_syrk_diff).
+constexpr int GM_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
+
+template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, const T* Cin, int ldcin,
+               T* C, int ldc, int K, int ntc, int tri, T alpha, int beta, int n_true, T diag_add) {
+    using M = Mfma<T>;
+    using acc_t = typename M::acc_t;
+    using frag_t = typename M::frag_t;
+    constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
+    constexpr int EPL = M::EPL;
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int NA = BM * 8 / 256, NBI = BN * 8 / 256;  // 16-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                       // [2][BM][GM_ROWB]
+    char* Bs = smem + 2 * BM * GM_ROWB;    // [2][BN][GM_ROWB]
+
+    // ---- tile decode
+    int ti, tj;
+    {
+        const int b = blockIdx.x;
+        if (tri) {
+            const int T3 = ntc * (ntc + 1) / 2;
+            if (b < T3) {
+                ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+                while (ti * (ti + 1) / 2 > b) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+                tj = b - ti * (ti + 1) / 2;
+            } else {
+                const int bb = b - T3;
+                ti = ntc + bb / ntc;
+                tj = bb % ntc;
+            }
+        } else {
+            ti = b / ntc;
+            tj = b % ntc;
+        }
+    }
+    const int row0 = ti * BM, col0 = tj * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WGN, wn = wv % WGN;
+    const int r = lane & 15, q = lane >> 4;
+
+    acc_t acc[TM][TN];
+    if (beta) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[mi][ni][e] = Cin[(size_t)(row0 + (wm * TM + mi) * 16 + M::crow(q, e)) * ldcin + col0 +
+                                         (wn * TN + ni) * 16 + r];
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = acc_zero<T>();
+    }
+
+    const T* Ag = A + (size_t)row0 * lda;
+    const T* Bg = B + (size_t)col0 * ldb;
+    frag_t pa[NA], pb[NBI];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + 256 * i;
+            pa[i] = *reinterpret_cast<const frag_t*>(Ag + (size_t)(c >> 3) * lda + k0 + (c & 7) * EPL);
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int c = tid + 256 * i;
+            pb[i] = *reinterpret_cast<const frag_t*>(Bg + (size_t)(c >> 3) * ldb + k0 + (c & 7) * EPL);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int c = tid + 256 * i;
+            frag_t v = pa[i];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] *= alpha;
+            *reinterpret_cast<frag_t*>(As + ((size_t)buf * BM + (c >> 3)) * GM_ROWB + (c & 7) * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<frag_t*>(Bs + ((size_t)buf * BN + (c >> 3)) * GM_ROWB + (c & 7) * 16) = pb[i];
+        }
+    };
+
+    const int nk = K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        const char* Ab = As + ((size_t)cur * BM + wm * TM * 16 + r) * GM_ROWB + q * 16;
+        const char* Bb = Bs + ((size_t)cur * BN + wn * TN * 16 + r) * GM_ROWB + q * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            frag_t af[TM], bf[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                af[mi] = *reinterpret_cast<const frag_t*>(Ab + mi * 16 * GM_ROWB + kc * 64);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                bf[ni] = *reinterpret_cast<const frag_t*>(Bb + ni * 16 * GM_ROWB + kc * 64);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = M::mma(af[mi][e], bf[ni][e], acc[mi][ni]);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gr = row0 + (wm * TM + mi) * 16 + M::crow(q, e);
+                const int gc = col0 + (wn * TN + ni) * 16 + r;
+                T v = acc[mi][ni][e];
+                if (EPI) {
+                    if (gr == gc) v += diag_add;
+                    if (gr >= n_true || gc >= n_true) v = (gr == gc) ? (T)1 : (T)0;
+                }
+                C[(size_t)gr * ldc + gc] = v;
+            }
+}
+
+template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
+static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, int ldcin, T* C, int ldc, int mrows,
+                       int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s) {
+    constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
+    constexpr int BK = 128 / (int)sizeof(T);
+    if (mrows <= 0 || ncols <= 0) return 0;
+    if (mrows % BM || ncols % BN || K % BK || K <= 0)
+        return fail(-1, "launch_gemm: shape %dx%dx%d not tileable by %dx%dx%d", mrows, ncols, K, BM, BN, BK);
+    const int mt = mrows / BM, ntc = ncols / BN;
+    int nblk;
+    if (tri) {
+        if (BM != BN || mt < ntc) return fail(-1, "launch_gemm: bad triangular shape");
+        nblk = ntc * (ntc + 1) / 2 + (mt - ntc) * ntc;
+    } else {
+        nblk = mt * ntc;
+    }
+    const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
+    auto kern = gemm_nt_kernel<T, WGM, WGN, TM, TN, EPI>;
+    static bool attr_done = false;  // per template instantiation
+    if (!attr_done) {
+        GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri, alpha,
+                       beta, n_true, diag_add);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// C(mrows x ncols region) -= A A_j^T, big (128x128) or small (64x64) tiles by problem size
+template <typename T>
+static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi) {
+    // update columns [col_lo, col_hi) of the trailing matrix (rows >= col_lo), K = nbk panel at k0
+    const int rows = mp - col_lo;
+    const int cols = col_hi - col_lo;
+    const T* P = W + (size_t)col_lo * ld + k0;
+    T* C = W + (size_t)col_lo * ld + col_lo;
+    if (rows > g_opt.small_tile_m)
+        return launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+    return launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+}
+
+// factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks
+template <typename T>
+static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, hipStream_t s) {
+    for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
+        if (c0 > k0) {  // rows [c0, mp) x cols [c0, c0+64) -= L[rows, k0:c0] L[c0:c0+64, k0:c0]^T
+            const T* Ap = W + (size_t)c0 * ld + k0;
+            T* Cp = W + (size_t)c0 * ld + c0;
+            int rc = launch_gemm<T, 2, 2, 2, 2, false>(Ap, ld, Ap, ld, Cp, ld, Cp, ld, mp - c0, NB_IN, c0 - k0, 0,
+                                                       (T)-1, 1, 0, (T)0, s);
+            if (rc) return rc;
+        }
+        T* Wd = W + (size_t)c0 * ld + c0;
+        hipLaunchKernelGGL((diag_factor_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
+        GPMC_LAUNCH_CHECK();
+        const int below = mp - c0 - NB_IN;
+        if (below > 0) {
+            hipLaunchKernelGGL((trsm_strip_kernel<T>), dim3(below / 64), dim3(256), 0, s,
+                               W + (size_t)(c0 + NB_IN) * ld + c0, ld, Wd, dinv);
+            GPMC_LAUNCH_CHECK();
+        }
+        dinv += 4 * 256;  // each diagonal block keeps its own inverse tiles (no WAR hazard across streams)
+    }
+    return 0;
+}
+
+template <typename T>
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s) {
+    GPMC_ARG(W != nullptr, 1);
+    GPMC_ARG(np_ > 0 && np_ % GPMC_PAD == 0, 3);
+    GPMC_ARG(mp >= np_ && mp % GPMC_PAD == 0, 2);
+    GPMC_ARG(ldw >= np_ && ldw % (16 / (int)sizeof(T)) == 0, 4);
+    GPMC_ARG(info_dev != nullptr, 5);
+    GPMC_ARG(scratch != nullptr, 6);
+    GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
+    T* dinv = reinterpret_cast<T*>(scratch);
+    int NB = g_opt.outer_nb;
+    if (NB < 128 || NB % 128) NB = 256;
+    GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+
+    if (!g_opt.lookahead || np_ <= NB) {
+        for (int k0 = 0; k0 < np_; k0 += NB) {
+            const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
+            int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, s);
+            if (rc) return rc;
+            const int k1 = k0 + nbk;
+            if (k1 < np_) {
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+                if (rc) return rc;
+            }
+        }
+        return 0;
+    }
+
+    // ---- look-ahead: after panel k, update only the next panel's columns first (on s), then factor
+    // panel k+1 on the high-priority panel stream while the remaining columns are updated on s.
+    Aux* ax;
+    {
+        int rc = aux_get(&ax);
+        if (rc) return rc;
+    }
+    hipStream_t ps = ax->panel_stream;
+    int evi = 0;
+    auto next_ev = [&]() { hipEvent_t e = ax->ev[evi]; evi = (evi + 1) % 8; return e; };
+    // panel 0 on the main stream
+    {
+        const int nbk = (np_ < NB) ? np_ : NB;
+        int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, s);
+        if (rc) return rc;
+    }
+    for (int k0 = 0; k0 < np_; k0 += NB) {
+        const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
+        const int k1 = k0 + nbk;
+        if (k1 >= np_) break;
+        const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;  // next panel width
+        // (1) next panel's columns, on s
+        int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn);
+        if (rc) return rc;
+        hipEvent_t e1 = next_ev();
+        GPMC_HIP(hipEventRecord(e1, s));
+        // (2) factor next panel on ps
+        GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
+        rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, ps);
+        if (rc) return rc;
+        hipEvent_t e2 = next_ev();
+        GPMC_HIP(hipEventRecord(e2, ps));
+        // (3) the rest of the trailing matrix, on s, concurrently with (2)
+        if (k1 + nbn < np_) {
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1 + nbn, np_);
+            if (rc) return rc;
+        }
+        GPMC_HIP(hipStreamWaitEvent(s, e2, 0));
+    }
+    return 0;
+}
+
+template <typename T>
+int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_, int ldc,
+              hipStream_t s) {
+    GPMC_ARG(D && P && C, 1);
+    GPMC_ARG(kp > 0 && kp % GPMC_PAD == 0 && ldp >= kp, 3);
+    GPMC_ARG(n > 0 && n <= np_ && np_ % GPMC_PAD == 0, 8);
+    GPMC_ARG(ldc >= np_ && ldd >= np_, 10);
+    if (np_ > g_opt.small_tile_m)
+        return launch_gemm<T, 2, 2, 4, 4, true>(P, ldp, P, ldp, D, ldd, C, ldc, np_, np_, kp, 1, (T)-1, 1, n, diag_add, s);
+    return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, D, ldd, C, ldc, np_, np_, kp, 1, (T)-1, 1, n, diag_add, s);
+}
+
+template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t);
+template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t);
+template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);
+template int syrk_diff<float>(const float*, int, const float*, int, int, float, float*, int, int, int, hipStream_t);
+
+}  // namespace gpmc

@@ -1,0 +1,202 @@
+// reduce.hip -- O(N^2)/O(N) companions of the factorisation (8(b) packing).
+#include "gpmc_common.h"
+
+namespace gpmc {
+
+// ----------------------------------------------------------------------- log-marginal reduction
+// curG / propG of kcMCMC/sliceSample.py:122,147 from the factor: -(0.5 a.a + sum log L_ii + n/2 log 2pi)
+// One workgroup, fixed summation order (bitwise reproducible), f64 accumulation for both types.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ alpha,
+                   const int* __restrict__ info, double* __restrict__ out) {
+    __shared__ double s_ld[1024], s_q[1024];
+    const int tid = threadIdx.x;
+    double ld = 0.0, qd = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        ld += log((double)W[(size_t)i * ldw + i]);
+        const double a = (double)alpha[i];
+        qd += a * a;
+    }
+    s_ld[tid] = ld;
+    s_q[tid] = qd;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (tid < st) {
+            s_ld[tid] += s_ld[tid + st];
+            s_q[tid] += s_q[tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double LOG_2PI = 1.8378770664093454835606594728112;
+        out[0] = -(0.5 * s_q[0] + s_ld[0] + 0.5 * (double)n * LOG_2PI);
+        out[1] = s_ld[0];
+        out[2] = s_q[0];
+        out[3] = info ? (double)info[0] : 0.0;
+    }
+}
+
+template <typename T>
+int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s) {
+    GPMC_ARG(W && n > 0 && ldw >= n, 1);
+    GPMC_ARG(alpha != nullptr, 4);
+    GPMC_ARG(out_dev != nullptr, 6);
+    hipLaunchKernelGGL((logdet_quad_kernel<T>), dim3(1), dim3(1024), 0, s, W, n, ldw, alpha, info_dev, out_dev);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------- packing
+template <typename T>
+__global__ void pack_lower_kernel(const T* __restrict__ A, int n, int lda, T jitter, T* __restrict__ W, int np_,
+                                  int ldw) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= np_) return;
+    T v = (T)0;
+    if (j <= i) {
+        if (i < n) v = A[(size_t)i * lda + j] + ((i == j) ? jitter : (T)0);
+        else v = (i == j) ? (T)1 : (T)0;
+    }
+    W[(size_t)i * ldw + j] = v;
+}
+template <typename T>
+__global__ void pack_rows_kernel(const T* __restrict__ B, int nrhs, int n, int ldb, T* __restrict__ W, int np_,
+                                 int ldw) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= np_) return;
+    W[(size_t)(np_ + r) * ldw + j] = (r < nrhs && j < n) ? B[(size_t)r * ldb + j] : (T)0;
+}
+template <typename T>
+__global__ void unpack_lower_kernel(const T* __restrict__ W, int ldw, T* __restrict__ L, int n, int ldl) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    L[(size_t)i * ldl + j] = (j <= i) ? W[(size_t)i * ldw + j] : (T)0;
+}
+template <typename T>
+__global__ void unpack_rows_kernel(const T* __restrict__ W, int np_, int ldw, T* __restrict__ B, int n, int ldb) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= n) return;
+    B[(size_t)r * ldb + j] = W[(size_t)(np_ + r) * ldw + j];
+}
+
+template <typename T>
+int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s) {
+    GPMC_ARG(A && n > 0 && lda >= n, 1);
+    GPMC_ARG(W && np_ >= n && np_ % GPMC_PAD == 0 && ldw >= np_, 5);
+    hipLaunchKernelGGL((pack_lower_kernel<T>), dim3((np_ + 255) / 256, np_), dim3(256), 0, s, A, n, lda, jitter, W,
+                       np_, ldw);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int pack_rows(const T* B, int nrhs, int n, int ldb, T* W, int mp, int np_, int ldw, hipStream_t s) {
+    GPMC_ARG(nrhs >= 0 && (nrhs == 0 || (B && ldb >= n)), 1);
+    GPMC_ARG(W && mp >= np_ + nrhs && ldw >= np_, 5);
+    if (mp == np_) return 0;
+    hipLaunchKernelGGL((pack_rows_kernel<T>), dim3((np_ + 255) / 256, mp - np_), dim3(256), 0, s, B, nrhs, n, ldb,
+                       W, np_, ldw);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int unpack_lower(const T* W, int np_, int ldw, T* L, int n, int ldl, hipStream_t s) {
+    GPMC_ARG(W && L && n > 0 && n <= np_ && ldl >= n && ldw >= np_, 1);
+    hipLaunchKernelGGL((unpack_lower_kernel<T>), dim3((n + 255) / 256, n), dim3(256), 0, s, W, ldw, L, n, ldl);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int unpack_rows(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, hipStream_t s) {
+    GPMC_ARG(W && B && nrhs > 0 && n > 0 && n <= np_ && ldb >= n, 1);
+    hipLaunchKernelGGL((unpack_rows_kernel<T>), dim3((n + 255) / 256, nrhs), dim3(256), 0, s, W, np_, ldw, B, n, ldb);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------- matrix-vector products
+// symv_lower: y = A x from the lower triangle only.  Workgroup b owns rows/columns I = [64b, 64b+64):
+//   row part    sum_{j <= i} A[i][j] x[j]   (rows of I, coalesced along j)
+//   column part sum_{j >  I} A[j][i] x[j]   (rows below I, 64-wide coalesced segments)
+// Fixed summation order; every lower element is read twice in total (HBM-bound, 2 * s * N^2/2 bytes).
+template <typename T>
+__global__ void __launch_bounds__(256)
+symv_lower_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ x, T* __restrict__ y) {
+    __shared__ double part[4][64];
+    __shared__ double rowsum[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = blockIdx.x * 64;
+    // row part
+    for (int rr = wv; rr < 64; rr += 4) {
+        const int i = i0 + rr;
+        double s = 0.0;
+        if (i < n)
+            for (int j = lane; j <= i; j += 64) s += (double)W[(size_t)i * ldw + j] * (double)x[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) rowsum[rr] = s;
+    }
+    // column part
+    {
+        const int i = i0 + lane;
+        double s = 0.0;
+        if (i < n)
+            for (int j = i0 + 64 + wv; j < n; j += 4) s += (double)W[(size_t)j * ldw + i] * (double)x[j];
+        // rows of the diagonal block below the diagonal: j in (i, i0+64)
+        if (i < n)
+            for (int j = i + 1 + wv; j < min(i0 + 64, n); j += 4) s += (double)W[(size_t)j * ldw + i] * (double)x[j];
+        part[wv][lane] = s;
+    }
+    __syncthreads();
+    if (tid < 64 && i0 + tid < n)
+        y[i0 + tid] = (T)(rowsum[tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])));
+}
+
+// trmv_lower: y = L x + y0 (y0 may be null), one wave per row.
+template <typename T>
+__global__ void __launch_bounds__(256)
+trmv_lower_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ x, const T* __restrict__ y0,
+                  T* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = lane; j <= i; j += 64) s += (double)W[(size_t)i * ldw + j] * (double)x[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[i] = (T)(s + (y0 ? (double)y0[i] : 0.0));
+}
+
+template <typename T>
+int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s) {
+    GPMC_ARG(W && n > 0 && ldw >= n, 1);
+    GPMC_ARG(x && y && x != y, 4);
+    hipLaunchKernelGGL((symv_lower_kernel<T>), dim3((n + 63) / 64), dim3(256), 0, s, W, n, ldw, x, y);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStream_t s) {
+    GPMC_ARG(W && n > 0 && ldw >= n, 1);
+    GPMC_ARG(x && y && x != y, 4);
+    hipLaunchKernelGGL((trmv_lower_kernel<T>), dim3((n + 3) / 4), dim3(256), 0, s, W, n, ldw, x, y0, y);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
+#define INST(T)                                                                                              \
+    template int logdet_quad<T>(const T*, int, int, const T*, const int*, double*, hipStream_t);             \
+    template int pack_lower<T>(const T*, int, int, T, T*, int, int, hipStream_t);                            \
+    template int pack_rows<T>(const T*, int, int, int, T*, int, int, int, hipStream_t);                      \
+    template int unpack_lower<T>(const T*, int, int, T*, int, int, hipStream_t);                             \
+    template int unpack_rows<T>(const T*, int, int, T*, int, int, int, hipStream_t);                         \
+    template int symv_lower<T>(const T*, int, int, const T*, T*, hipStream_t);                               \
+    template int trmv_lower<T>(const T*, int, int, const T*, const T*, T*, hipStream_t);
+INST(double)
+INST(float)
+
+}  // namespace gpmc

@@ -1,0 +1,105 @@
+"""ctypes binding of libgpmc.so (the C ABI declared in include/gpmc.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgpmc.so')
+CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
+
+KERNEL_RBF = 0
+KERNEL_MATERN52_ARD = 1
+KB_FULL = 0
+KB_LOWER = 1
+KB_PAD_IDENTITY = 2
+PAD = 128
+
+c_int, c_void_p, c_double, c_float, c_size_t, c_char_p = (ctypes.c_int, ctypes.c_void_p, ctypes.c_double,
+                                                          ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p)
+
+
+class GpmcError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libgpmc.so in-tree with hipcc for gfx950 (seconds; works without a GPU)."""
+    if force:
+        subprocess.check_call(['make', '-C', CSRC, 'clean'])
+    subprocess.check_call(['make', '-C', CSRC, '-j4'])
+    return LIB_PATH
+
+
+def _sig(lib):
+    P, I = c_void_p, c_int
+    kb = [I, P, I, I, I, P, I, I, P, P, I, I, I, I, P]
+    table = {
+        'gpmc_version': ([], I),
+        'gpmc_last_error': ([], c_char_p),
+        'gpmc_pad': ([I], I),
+        'gpmc_potrf_scratch_bytes': ([I], c_size_t),
+        'gpmc_kbuild_f64': (kb, I), 'gpmc_kbuild_f32': (kb, I),
+        'gpmc_potrf_f64': ([P, I, I, I, P, P, P], I), 'gpmc_potrf_f32': ([P, I, I, I, P, P, P], I),
+        'gpmc_logdet_quad_f64': ([P, I, I, P, P, P, P], I), 'gpmc_logdet_quad_f32': ([P, I, I, P, P, P, P], I),
+        'gpmc_pack_lower_f64': ([P, I, I, c_double, P, I, I, P], I),
+        'gpmc_pack_lower_f32': ([P, I, I, c_float, P, I, I, P], I),
+        'gpmc_pack_rows_f64': ([P, I, I, I, P, I, I, I, P], I), 'gpmc_pack_rows_f32': ([P, I, I, I, P, I, I, I, P], I),
+        'gpmc_unpack_lower_f64': ([P, I, I, P, I, I, P], I), 'gpmc_unpack_lower_f32': ([P, I, I, P, I, I, P], I),
+        'gpmc_unpack_rows_f64': ([P, I, I, P, I, I, I, P], I), 'gpmc_unpack_rows_f32': ([P, I, I, P, I, I, I, P], I),
+        'gpmc_syrk_diff_f64': ([P, I, P, I, I, c_double, P, I, I, I, P], I),
+        'gpmc_syrk_diff_f32': ([P, I, P, I, I, c_float, P, I, I, I, P], I),
+        'gpmc_symv_lower_f64': ([P, I, I, P, P, P], I), 'gpmc_symv_lower_f32': ([P, I, I, P, P, P], I),
+        'gpmc_trmv_lower_f64': ([P, I, I, P, P, P, P], I), 'gpmc_trmv_lower_f32': ([P, I, I, P, P, P, P], I),
+        'gpmc_plan_workspace_bytes': ([I, I, I], c_size_t),
+        'gpmc_plan_create': ([ctypes.POINTER(c_void_p), I, I, I, I, P, c_size_t, P], I),
+        'gpmc_plan_set_data': ([P, P, I, P], I),
+        'gpmc_plan_logml_async': ([P, ctypes.POINTER(c_double), I, I], I),
+        'gpmc_plan_result': ([P, I, ctypes.POINTER(c_double)], I),
+        'gpmc_plan_workspace': ([P, ctypes.POINTER(c_void_p), ctypes.POINTER(I), ctypes.POINTER(I),
+                                 ctypes.POINTER(I)], I),
+        'gpmc_plan_destroy': ([P], I),
+        'gpmc_set_option': ([c_char_p, I], I),
+        'gpmc_get_option': ([c_char_p], I),
+    }
+    for name, (argtypes, restype) in table.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return sorted(table)
+
+
+_lib = None
+EXPORTS = None
+
+
+def lib():
+    """The loaded library; raises GpmcError when it has not been built."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpmcError('libgpmc.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback)' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        EXPORTS = _sig(_lib)
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().gpmc_last_error()
+        raise GpmcError('%s failed (rc=%d): %s' % (what or 'libgpmc call', rc, msg.decode() if msg else '?'))
+
+
+def set_option(name, value):
+    check(lib().gpmc_set_option(name.encode(), int(value)), 'gpmc_set_option')
+
+
+def get_option(name):
+    return lib().gpmc_get_option(name.encode())
+
+
+def pad(n):
+    return (int(n) + PAD - 1) // PAD * PAD

@@ -1,0 +1,103 @@
+"""The metric's unit as a function: one GP log-marginal evaluation at fresh hyper-parameters.
+
+``log N(g; 0, K(hyp) + S)`` = the ``curG`` / ``propG`` expression of kcMCMC/sliceSample.py:122,147 with the
+K build (sliceSample.py:136-137), the S diagonal (:183-190) and the Cholesky (:196) behind it.  The
+reference inlines this in its sampler loop; here it is a plan object bound to (X, g) whose per-call
+host cost is one hipGraph launch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, covK, ops
+
+_ES = {torch.float64: 8, torch.float32: 4}
+
+
+class LogMarginalPlan(object):
+    def __init__(self, X, g, kernel='rbf', dtype=torch.float64):
+        ops.require_gpu()
+        self.kernel = kernel
+        self.dtype = dtype
+        self.X = ops.to_dev(X, dtype)
+        if self.X.dim() == 1:
+            self.X = self.X.reshape(-1, 1)
+        self.g = ops.to_dev(g, dtype).reshape(-1)
+        self.n, self.d = self.X.shape
+        if self.g.shape[0] != self.n:
+            raise ValueError('g must have one entry per row of X')
+        L = _lib.lib()
+        nbytes = L.gpmc_plan_workspace_bytes(self.n, self.d, _ES[dtype])
+        if nbytes == 0:
+            raise _lib.GpmcError('gpmc_plan_workspace_bytes rejected n=%d d=%d' % (self.n, self.d))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.X.device)  # caller-owned memory
+        self._stream = torch.cuda.current_stream()
+        h = ctypes.c_void_p()
+        _lib.check(L.gpmc_plan_create(ctypes.byref(h), ops.KERNELS[kernel], self.n, self.d, _ES[dtype],
+                                      self.workspace.data_ptr(), nbytes, self._stream.cuda_stream), 'gpmc_plan_create')
+        self._h = h
+        _lib.check(L.gpmc_plan_set_data(h, self.X.data_ptr(), self.X.stride(0), self.g.data_ptr()),
+                   'gpmc_plan_set_data')
+
+    def set_g(self, g):
+        self.g = ops.to_dev(g, self.dtype).reshape(-1)
+        _lib.check(_lib.lib().gpmc_plan_set_data(self._h, self.X.data_ptr(), self.X.stride(0), self.g.data_ptr()),
+                   'gpmc_plan_set_data')
+
+    def kparams(self, hyp):
+        """sampler hyp (ell.., sf, sn), linear scale -> [sf2, Sii, ell..] exactly as the oracle forms them"""
+        kobj, sn = covK.kernel_from_hyp(hyp, self.kernel, self.dtype)
+        kp = kobj.kparams()
+        kp[1] = covK.s_diag_scalar(kp[0], sn)
+        return kp
+
+    def eval_async(self, hyp, slot=0):
+        kp = np.ascontiguousarray(self.kparams(hyp), dtype=np.float64)
+        _lib.check(_lib.lib().gpmc_plan_logml_async(self._h, kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                    kp.shape[0], slot), 'gpmc_plan_logml_async')
+
+    def result(self, slot=0):
+        """(logml, logdet, quad, info) of the evaluation enqueued into ``slot``; synchronises the stream."""
+        out = (ctypes.c_double * 4)()
+        _lib.check(_lib.lib().gpmc_plan_result(self._h, slot, out), 'gpmc_plan_result')
+        return float(out[0]), float(out[1]), float(out[2]), int(out[3])
+
+    def __call__(self, hyp):
+        self.eval_async(hyp, 0)
+        lml, _, _, info = self.result(0)
+        if info != 0:
+            raise np.linalg.LinAlgError('K + S not positive definite at pivot %d for hyp=%r' % (info, list(hyp)))
+        return lml
+
+    def factor_view(self):
+        """(W, mp, np_, ld): the factored workspace of the last evaluation (L in the lower triangle,
+        alpha = L^-1 g in row np_)."""
+        W = ctypes.c_void_p()
+        mp, np_, ld = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().gpmc_plan_workspace(self._h, ctypes.byref(W), ctypes.byref(mp), ctypes.byref(np_),
+                                                  ctypes.byref(ld)), 'gpmc_plan_workspace')
+        off = W.value - self.workspace.data_ptr()
+        es = _ES[self.dtype]
+        view = self.workspace[off:off + mp.value * ld.value * es].view(self.dtype).view(mp.value, ld.value)
+        return view, mp.value, np_.value, ld.value
+
+    def close(self):
+        if getattr(self, '_h', None) is not None:
+            _lib.lib().gpmc_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def log_marginal(X, g, hyp, kernel='rbf', dtype=torch.float64):
+    """One-shot convenience: log N(g; 0, K(hyp) + S).  Build a LogMarginalPlan for repeated calls."""
+    plan = LogMarginalPlan(X, g, kernel, dtype)
+    try:
+        return plan(hyp)
+    finally:
+        plan.close()

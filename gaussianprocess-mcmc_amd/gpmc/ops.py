@@ -1,0 +1,120 @@
+"""Typed wrappers over the C ABI: torch tensors in, raw device pointers + the current HIP stream out.
+
+torch is the device container only (memory, streams); every arithmetic op below is a libgpmc kernel.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KB_FULL, KB_LOWER, KB_PAD_IDENTITY, KERNEL_MATERN52_ARD, KERNEL_RBF, check, pad  # noqa: F401
+
+KERNELS = {'rbf': KERNEL_RBF, 'matern52ard': KERNEL_MATERN52_ARD}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.GpmcError('no HIP device visible: the gpmc product path is GPU-only (no CPU fallback)')
+
+
+def device():
+    require_gpu()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def sfx(dtype):
+    if dtype == torch.float64:
+        return 'f64'
+    if dtype == torch.float32:
+        return 'f32'
+    raise TypeError('gpmc supports float64 and float32, got %r' % (dtype,))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_dev(a, dtype=torch.float64):
+    """ndarray / list / tensor -> contiguous device tensor of dtype (no copy when already there)."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device(), dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device())
+
+
+def _fn(name, dtype):
+    return getattr(_lib.lib(), 'gpmc_%s_%s' % (name, sfx(dtype)))
+
+
+def kbuild(kernel, X, kparams_dev, out, n_rows, n_cols, flags, Z=None):
+    """out[0:rows_out, 0:cols_out] <- k(X, Z) per include/gpmc.h (out is a 2-D row-major view)."""
+    dt = X.dtype
+    n, d = X.shape
+    nz = 0 if Z is None else Z.shape[0]
+    check(_fn('kbuild', dt)(KERNELS[kernel] if isinstance(kernel, str) else kernel,
+                            X.data_ptr(), n, d, X.stride(0),
+                            0 if Z is None else Z.data_ptr(), nz, 0 if Z is None else Z.stride(0),
+                            kparams_dev.data_ptr(), out.data_ptr(), n_rows, n_cols, out.stride(0), flags,
+                            stream_ptr()), 'gpmc_kbuild')
+    return out
+
+
+def potrf(W, mp, np_, info, scratch):
+    check(_fn('potrf', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), info.data_ptr(), scratch.data_ptr(),
+                                stream_ptr()), 'gpmc_potrf')
+
+
+def logdet_quad(W, n, alpha, info, out):
+    check(_fn('logdet_quad', W.dtype)(W.data_ptr(), n, W.stride(0), alpha.data_ptr(),
+                                      0 if info is None else info.data_ptr(), out.data_ptr(), stream_ptr()),
+          'gpmc_logdet_quad')
+
+
+def pack_lower(A, W, np_, jitter=0.0):
+    n = A.shape[0]
+    check(_fn('pack_lower', A.dtype)(A.data_ptr(), n, A.stride(0), float(jitter), W.data_ptr(), np_, W.stride(0),
+                                     stream_ptr()), 'gpmc_pack_lower')
+
+
+def pack_rows(B, W, mp, np_, n):
+    """B: (nrhs, n) rows, or None to zero the riding rows."""
+    nrhs = 0 if B is None else B.shape[0]
+    check(_fn('pack_rows', W.dtype)(0 if B is None else B.data_ptr(), nrhs, n, 0 if B is None else B.stride(0),
+                                    W.data_ptr(), mp, np_, W.stride(0), stream_ptr()), 'gpmc_pack_rows')
+
+
+def unpack_lower(W, np_, n, out=None):
+    if out is None:
+        out = torch.empty((n, n), dtype=W.dtype, device=W.device)
+    check(_fn('unpack_lower', W.dtype)(W.data_ptr(), np_, W.stride(0), out.data_ptr(), n, out.stride(0),
+                                       stream_ptr()), 'gpmc_unpack_lower')
+    return out
+
+
+def unpack_rows(W, np_, nrhs, n, out=None):
+    if out is None:
+        out = torch.empty((nrhs, n), dtype=W.dtype, device=W.device)
+    check(_fn('unpack_rows', W.dtype)(W.data_ptr(), np_, W.stride(0), out.data_ptr(), nrhs, n, out.stride(0),
+                                      stream_ptr()), 'gpmc_unpack_rows')
+    return out
+
+
+def syrk_diff(D, P, kp, C, n, np_, diag_add=0.0):
+    check(_fn('syrk_diff', C.dtype)(D.data_ptr(), D.stride(0), P.data_ptr(), kp, P.stride(0), float(diag_add),
+                                    C.data_ptr(), n, np_, C.stride(0), stream_ptr()), 'gpmc_syrk_diff')
+
+
+def symv_lower(W, n, x, y):
+    check(_fn('symv_lower', W.dtype)(W.data_ptr(), n, W.stride(0), x.data_ptr(), y.data_ptr(), stream_ptr()),
+          'gpmc_symv_lower')
+    return y
+
+
+def trmv_lower(W, n, x, y0, y):
+    check(_fn('trmv_lower', W.dtype)(W.data_ptr(), n, W.stride(0), x.data_ptr(),
+                                     0 if y0 is None else y0.data_ptr(), y.data_ptr(), stream_ptr()),
+          'gpmc_trmv_lower')
+    return y
+
+
+def potrf_scratch(np_, dev):
+    nbytes = _lib.lib().gpmc_potrf_scratch_bytes(np_)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -1,0 +1,165 @@
+/* gpmc.h -- C ABI of libgpmc.so: MI355X (gfx950) GP-likelihood core.
+ *
+ * Drop-in boundary for the hot path of t-kychen/GaussianProcess-MCMC (the reference is pure
+ * Python; what it binds at this boundary is the `kcGP` object protocol and NumPy/LAPACK calls,
+ * cited per entry point as <reference file>:<line>).  Plain pointers and sizes only; no torch
+ * types.  All pointers named *_dev / W / K / X ... are DEVICE pointers owned by the caller; the
+ * library allocates no persistent memory, launches everything on the caller's stream and never
+ * synchronises unless the function says so.  Matrices are ROW-MAJOR (C order, as NumPy hands them
+ * to the reference) with an explicit leading dimension in elements.
+ *
+ * Return value: 0 = ok, <0 = bad argument (-k: k-th argument), >0 = hipError_t of a failed call.
+ * gpmc_last_error() returns a thread-local message for the last non-zero return.
+ *
+ * "Workspace matrix" W (factorisation input/output): mp x np_ elements, ld >= np_, with
+ *   np_ = gpmc_pad(n)   columns (multiple of GPMC_PAD), rows 0..np_-1 hold the symmetric matrix's
+ *                       LOWER triangle, identity on the padding,
+ *   rows np_..mp-1      optional extra rows ("right-hand sides", transposed): after
+ *                       gpmc_potrf_* they hold rows * L^-T, i.e. row r becomes (L^-1 b_r)^T.
+ *   mp multiple of GPMC_PAD.
+ */
+#ifndef GPMC_H
+#define GPMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMC_VERSION 100 /* 0.1.0 */
+#define GPMC_PAD 128     /* row/column padding granule of workspace matrices */
+
+typedef void* gpmc_stream_t; /* hipStream_t */
+
+/* kernel families (covK.<Kernel>) */
+enum { GPMC_KERNEL_RBF = 0, GPMC_KERNEL_MATERN52_ARD = 1 };
+/* gpmc_kbuild flags */
+enum {
+    GPMC_KB_FULL = 0,       /* write every entry                                           */
+    GPMC_KB_LOWER = 1,      /* write only tiles that touch the lower triangle (train mode) */
+    GPMC_KB_PAD_IDENTITY = 2 /* entries with i>=n or j>=nz: 1 on the diagonal, 0 elsewhere  */
+};
+
+int gpmc_version(void);
+const char* gpmc_last_error(void);
+/* padded size of an n x n problem */
+int gpmc_pad(int n);
+/* bytes of device scratch gpmc_potrf_* needs for a workspace of np_ columns */
+size_t gpmc_potrf_scratch_bytes(int np_);
+
+/* ---- a1: covariance build ------------------------------------------------------------------
+ * Replaces kcGP.covK.RBF(log_ell, log_sf).getCovMatrix(x=, z=, mode='train'|'cross')
+ * (call sites kcMCMC/sliceSample.py:104-105,136-137,255,263; demoRegression.py:124-125) and the
+ * dense-S diagonal of aux_var_model (sliceSample.py:183-190) fused onto the diagonal.
+ *   K[i][j] = k(x_i, z_j) (+ diag_add if i == j and x is z)
+ * hyp_dev (device, T): [0] = sf^2, [1] = diag_add, [2..] = ell (1 value for RBF, d for ARD).
+ * X: n x d (ldx), Z: nz x d (ldz) or NULL (=X).  K: rows_out x cols_out (ldk) with
+ * rows_out >= n, cols_out >= nz: entries outside n x nz are padding (see flags).
+ */
+int gpmc_kbuild_f64(int kernel, const double* X, int n, int d, int ldx, const double* Z, int nz, int ldz,
+                    const double* hyp_dev, double* K, int rows_out, int cols_out, int ldk, int flags,
+                    gpmc_stream_t stream);
+int gpmc_kbuild_f32(int kernel, const float* X, int n, int d, int ldx, const float* Z, int nz, int ldz,
+                    const float* hyp_dev, float* K, int rows_out, int cols_out, int ldk, int flags,
+                    gpmc_stream_t stream);
+
+/* ---- a3/a4/a7/a9/a16: blocked Cholesky of a workspace matrix, with riding right-hand sides ---
+ * Replaces kcGP.tools.jitchol (sliceSample.py:196,205,257; LAPACK dpotrf underneath) and, through
+ * the extra rows, np.linalg.solve(L, .) (sliceSample.py:108,197) / tools.solve_chol's forward half
+ * (sliceSample.py:258).  In place: on return the lower triangle of W[0:np_,0:np_] is L, rows
+ * np_..mp-1 are rows * L^-T.  The strict upper triangle inside each 64x64 diagonal block is zeroed;
+ * other upper-triangle entries are not referenced and not written.
+ * info_dev (device int): 0, or 1-based index of the first non-positive pivot (LAPACK convention);
+ * the factorisation keeps running on garbage after a failure -- check info before using W.
+ * scratch: gpmc_potrf_scratch_bytes(np_) bytes of device memory.
+ */
+int gpmc_potrf_f64(double* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream);
+int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream);
+
+/* ---- a11: log-marginal reduction --------------------------------------------------------------
+ * Replaces the curG/propG expression of sliceSample.py:122,147 given the factor and alpha = L^-1 g:
+ *   out_dev[0] = -(0.5*sum_j alpha_j^2 + sum_i log L_ii + n/2 log 2pi),  [1] = sum log L_ii,
+ *   out_dev[2] = sum alpha^2, [3] = (double) *info_dev.
+ * diag of W[0:n,0:n]; alpha = n elements starting at alpha_dev.  Accumulates in f64 for both types.
+ */
+int gpmc_logdet_quad_f64(const double* W, int n, int ldw, const double* alpha_dev, const int* info_dev,
+                         double* out_dev, gpmc_stream_t stream);
+int gpmc_logdet_quad_f32(const float* W, int n, int ldw, const float* alpha_dev, const int* info_dev,
+                         double* out_dev, gpmc_stream_t stream);
+
+/* ---- packing between caller matrices and workspace matrices ------------------------------------
+ * pack:   W[0:np_,0:np_] <- lower triangle of A (n x n, lda) + jitter on the diagonal, identity
+ *         padding (the reference hands jitchol a dense symmetric ndarray; inputs are never mutated,
+ *         sliceSample.py:196,205).  rows: W[np_+r, 0:np_] <- B[r, 0:n] (nrhs rows, ldb), 0 padding,
+ *         for r < mp - np_ (rows beyond nrhs are zeroed).
+ * unpack: L (n x n, ldl) <- lower triangle of W, strict upper = 0 (jitchol's return convention,
+ *         callers rely on it at sliceSample.py:197).  rows: B[r, 0:n] <- W[np_+r, 0:n].
+ */
+int gpmc_pack_lower_f64(const double* A, int n, int lda, double jitter, double* W, int np_, int ldw,
+                        gpmc_stream_t stream);
+int gpmc_pack_rows_f64(const double* B, int nrhs, int n, int ldb, double* W, int mp, int np_, int ldw,
+                       gpmc_stream_t stream);
+int gpmc_unpack_lower_f64(const double* W, int np_, int ldw, double* L, int n, int ldl, gpmc_stream_t stream);
+int gpmc_unpack_rows_f64(const double* W, int np_, int ldw, double* B, int nrhs, int n, int ldb,
+                         gpmc_stream_t stream);
+int gpmc_pack_lower_f32(const float* A, int n, int lda, float jitter, float* W, int np_, int ldw,
+                        gpmc_stream_t stream);
+int gpmc_pack_rows_f32(const float* B, int nrhs, int n, int ldb, float* W, int mp, int np_, int ldw,
+                       gpmc_stream_t stream);
+int gpmc_unpack_lower_f32(const float* W, int np_, int ldw, float* L, int n, int ldl, gpmc_stream_t stream);
+int gpmc_unpack_rows_f32(const float* W, int np_, int ldw, float* B, int nrhs, int n, int ldb,
+                         gpmc_stream_t stream);
+
+/* ---- a5: SYRK-form difference  C = D - P P^T  (lower tiles) --------------------------------------
+ * Replaces R_theta = K - np.dot(V.T, V) (sliceSample.py:198) with P = V^T = K L^-T (the riding rows
+ * of gpmc_potrf).  C (np_ x np_, ldc) receives D - P P^T on tiles touching the lower triangle plus
+ * diag_add on the diagonal (R + 1e-11 I of sliceSample.py:205), identity on the padding (i >= n).
+ * D may alias C.  P: np_ x kp (ldp), kp multiple of GPMC_PAD.
+ */
+int gpmc_syrk_diff_f64(const double* D, int ldd, const double* P, int kp, int ldp, double diag_add, double* C,
+                       int n, int np_, int ldc, gpmc_stream_t stream);
+int gpmc_syrk_diff_f32(const float* D, int ldd, const float* P, int kp, int ldp, float diag_add, float* C,
+                       int n, int np_, int ldc, gpmc_stream_t stream);
+
+/* ---- a6/a10: symmetric / triangular matrix-vector products on workspace matrices ----------------
+ * symv_lower:  y = A_sym x   using only the lower triangle of A (n x n inside W)   (m = R (g/S), :204)
+ * trmv_lower:  y = L x + y0  with L the lower triangle                              (f' = C eta + m, :140)
+ */
+int gpmc_symv_lower_f64(const double* W, int n, int ldw, const double* x, double* y, gpmc_stream_t stream);
+int gpmc_trmv_lower_f64(const double* W, int n, int ldw, const double* x, const double* y0, double* y,
+                        gpmc_stream_t stream);
+int gpmc_symv_lower_f32(const float* W, int n, int ldw, const float* x, float* y, gpmc_stream_t stream);
+int gpmc_trmv_lower_f32(const float* W, int n, int ldw, const float* x, const float* y0, float* y,
+                        gpmc_stream_t stream);
+
+/* ---- fused plan: one log-marginal evaluation per call -------------------------------------------
+ * The metric's unit (a1 + a2 + a3 + a11): for hyper-parameters hyp (host, linear
+ * scale: ell[1 or d], sf, sn) build K + S into the plan's workspace, factor it with g riding as an
+ * extra row, reduce.  The launch sequence is captured once into a hipGraph per plan and replayed.
+ * All device memory is the caller's: `workspace` of gpmc_plan_workspace_bytes(n, d, elem_size).
+ */
+typedef struct gpmc_plan gpmc_plan;
+size_t gpmc_plan_workspace_bytes(int n, int d, int elem_size);
+int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, void* workspace,
+                     size_t workspace_bytes, gpmc_stream_t stream);
+/* X: n x d host or device row-major (copied into the workspace), g: n elements */
+int gpmc_plan_set_data(gpmc_plan* p, const void* X_dev, int ldx, const void* g_dev);
+/* asynchronous: enqueue one evaluation; result lands in the plan's device result slot `slot` (0..63) */
+int gpmc_plan_logml_async(gpmc_plan* p, const double* hyp_host, int nhyp, int slot);
+/* synchronise the plan's stream and read result slot: out_host[0]=logml, [1]=logdet, [2]=quad, [3]=info */
+int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
+/* device pointer / geometry of the factored workspace of the last evaluation (for callers that go on
+ * to use L): W, mp, np_, ld */
+int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
+int gpmc_plan_destroy(gpmc_plan* p);
+
+/* tuning knobs (process-wide): outer block (multiple of 128), look-ahead on/off, graph on/off */
+int gpmc_set_option(const char* name, int value);
+int gpmc_get_option(const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMC_H */

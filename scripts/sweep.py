@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Development sweep (not the judged bench): time gpmc log-marginal evals across N / options."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'gaussianprocess-mcmc_amd'))
+import gpmc  # noqa: E402
+from gpmc import core  # noqa: E402
+
+
+def time_plan(plan, hyps, reps):
+    for h in hyps[:2]:
+        plan(h)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        plan.eval_async(hyps[i % len(hyps)], i % 32)
+    plan.result((reps - 1) % 32)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [2048, 4096, 8192]
+    rng = np.random.RandomState(124)
+    hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [0.7, 12.0, 1.5], [3.0, 5.0, 2.0]]
+    for n in sizes:
+        X = rng.uniform(0, 10, (n, 2))
+        g = rng.standard_normal(n) * 5
+        for la, gr, nb, stm in ((0, 0, 256, 3072), (0, 1, 256, 3072), (1, 1, 256, 3072), (1, 1, 128, 3072),
+                                (1, 1, 512, 3072), (1, 1, 256, 0), (1, 1, 256, 100000)):
+            gpmc.set_option('lookahead', la), gpmc.set_option('use_graph', gr), gpmc.set_option('outer_nb', nb)
+            gpmc.set_option('small_tile_m', stm)
+            plan = core.LogMarginalPlan(X, g, 'rbf')
+            reps = 20 if n <= 4096 else 8
+            dt = time_plan(plan, hyps, reps)
+            tf = n ** 3 / 3 / dt / 1e12
+            print('n=%5d lookahead=%d graph=%d nb=%3d small_m=%6d : %8.3f ms/eval  %7.1f evals/s  %6.2f TF/s' %
+                  (n, la, gr, nb, stm, dt * 1e3, 1 / dt, tf), flush=True)
+            plan.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,179 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on seeded inputs.  -m gpu only."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import sds_ref                      # noqa: E402  (checker only)
+from oracle.kcgp_ref import covK as ocovK       # noqa: E402
+
+SIZES = [1, 7, 64, 65, 200, 455, 1000]
+
+
+@pytest.fixture(scope='module')
+def gp():
+    import gpmc
+    from gpmc import core, covK, ops, tools
+    ops.require_gpu()
+    return dict(gpmc=gpmc, core=core, covK=covK, ops=ops, tools=tools)
+
+
+def _x(n, d, seed=0):
+    return np.random.RandomState(seed).uniform(0., 10., (n, d))
+
+
+def _spd(n, seed=0, cond=1e4):
+    rng = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, -np.log10(cond), n)
+    return (Q * ev) @ Q.T + 0.0
+
+
+@pytest.mark.parametrize('n', SIZES)
+@pytest.mark.parametrize('d', [1, 2, 8, 11])
+def test_kbuild_rbf_train(gp, n, d):
+    x = _x(n, d, n + d)
+    ll, sf = 1.3, 7.0
+    K = gp['covK'].RBF(np.log(ll), np.log(sf)).getCovMatrix(x=x, mode='train').cpu().numpy()
+    Kref = ocovK.RBF(np.log(ll), np.log(sf)).getCovMatrix(x=x, mode='train')
+    assert K.shape == (n, n)
+    np.testing.assert_allclose(K, Kref, rtol=2e-14, atol=1e-300)      # fp64: a few ulp of exp()
+
+
+def test_kbuild_cross_selftest_and_diag(gp):
+    x, z = _x(300, 2, 1), _x(77, 2, 2)
+    k = gp['covK'].RBF(np.log(0.7), np.log(3.0))
+    ko = ocovK.RBF(np.log(0.7), np.log(3.0))
+    np.testing.assert_allclose(k.getCovMatrix(x=x, z=z, mode='cross').cpu().numpy(),
+                               ko.getCovMatrix(x=x, z=z, mode='cross'), rtol=2e-14)
+    np.testing.assert_allclose(k.getCovMatrix(z=z, mode='self_test').cpu().numpy(),
+                               ko.getCovMatrix(z=z, mode='self_test'), rtol=1e-15)
+    Kd = k.getCovMatrix(x=x, mode='train', diag_add=1.44).cpu().numpy()
+    np.testing.assert_allclose(Kd, ko.getCovMatrix(x=x, mode='train') + 1.44 * np.eye(300), rtol=2e-14)
+
+
+@pytest.mark.parametrize('n,d', [(64, 1), (200, 8), (333, 3)])
+def test_kbuild_matern_ard(gp, n, d):
+    x = _x(n, d, 5)
+    le = np.log(np.random.RandomState(3).uniform(0.5, 2.0, d))
+    K = gp['covK'].MaternARD52(le, np.log(2.0)).getCovMatrix(x=x, mode='train').cpu().numpy()
+    Kref = ocovK.MaternARD52(le, np.log(2.0)).getCovMatrix(x=x, mode='train')
+    np.testing.assert_allclose(K, Kref, rtol=1e-13, atol=1e-300)
+
+
+def test_kbuild_f32(gp):
+    x = _x(500, 8, 9)
+    le = np.log(np.random.RandomState(4).uniform(0.5, 2.0, 8))
+    K = gp['covK'].MaternARD52(le, np.log(2.0), dtype=torch.float32).getCovMatrix(x=x, mode='train').cpu().numpy()
+    Kref = ocovK.MaternARD52(le, np.log(2.0)).getCovMatrix(x=x, mode='train')
+    np.testing.assert_allclose(K, Kref, rtol=2e-5, atol=1e-6)          # fp32 inputs and exp
+
+
+@pytest.mark.parametrize('n', SIZES + [2048])
+def test_jitchol_matches_lapack(gp, n):
+    A = _spd(n, n)
+    L = gp['tools'].jitchol(A).cpu().numpy()
+    Lref = scipy.linalg.cholesky(A, lower=True)
+    assert np.all(np.triu(L, 1) == 0)
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-11 * np.abs(Lref).max())
+    res = np.abs(L @ L.T - A).max() / np.abs(A).max()
+    assert res < 1e-13
+
+
+def test_jitchol_does_not_mutate_and_takes_tensors(gp):
+    A = _spd(130, 3)
+    At = torch.as_tensor(A).cuda()
+    A0 = At.clone()
+    L = gp['tools'].jitchol(At)
+    assert torch.equal(At, A0) and L.is_cuda and L.shape == (130, 130)
+
+
+def test_jitchol_not_pd(gp):
+    with pytest.raises(np.linalg.LinAlgError):
+        gp['tools'].jitchol(-np.eye(5))
+    a = np.ones((6, 6))                          # rank one, positive diagonal: jitter path
+    L = gp['tools'].jitchol(a).cpu().numpy()
+    np.testing.assert_allclose(L @ L.T, a, atol=1e-6)
+    A = _spd(300, 1)
+    A[200, 200] = -1.0                           # first failing pivot is reported LAPACK-style (1-based)
+    ws = gp['tools'].FactorWorkspace(300)
+    gp['ops'].pack_lower(torch.as_tensor(A).cuda(), ws.W, ws.np_, 0.0)
+    ws.factor()
+    assert ws.info_host() == 201
+
+
+@pytest.mark.parametrize('n,nrhs', [(200, 1), (455, 3), (1000, 130), (1536, 1536)])
+def test_riding_rows_are_forward_solves(gp, n, nrhs):
+    """rows below the matrix come back as rows * L^-T = (L^-1 B)^T  (np.linalg.solve(L, .), sliceSample.py:108,197)"""
+    A = _spd(n, 7)
+    B = np.random.RandomState(8).standard_normal((nrhs, n))
+    ws = gp['tools'].FactorWorkspace(n, nrhs)
+    ops = gp['ops']
+    ops.pack_lower(torch.as_tensor(A).cuda(), ws.W, ws.np_, 0.0)
+    ops.pack_rows(torch.as_tensor(B).cuda(), ws.W, ws.mp, ws.np_, n)
+    ws.factor()
+    assert ws.info_host() == 0
+    V = ops.unpack_rows(ws.W, ws.np_, nrhs, n).cpu().numpy()
+    Lref = scipy.linalg.cholesky(A, lower=True)
+    Vref = scipy.linalg.solve_triangular(Lref, B.T, lower=True).T
+    np.testing.assert_allclose(V, Vref, rtol=0, atol=1e-9 * np.abs(Vref).max())
+
+
+@pytest.mark.parametrize('n,d', [(1, 1), (7, 1), (200, 1), (455, 1), (1000, 2), (2048, 2)])
+def test_log_marginal_matches_scipy(gp, n, d):
+    """north_star bar: log-marginal within 1e-8 relative of the NumPy/SciPy value (fp64)."""
+    x = _x(n, d, 10 + n)
+    rng = np.random.RandomState(n)
+    g = rng.standard_normal(n) * 5.
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    for hyp in ([1.0, 10.0, 1.2], [0.35, 2.0, 0.2], [4.1, 6.3, 2.7], [1.0, 10.0, 1.2]):
+        ref = sds_ref.gp_log_marginal(x, g, hyp)
+        got = plan(hyp)
+        assert abs(got - ref) <= 1e-8 * abs(ref), (n, hyp, got, ref)
+    plan.close()
+
+
+def test_log_marginal_options_agree(gp):
+    """look-ahead / graph replay / outer block size are schedules, not arithmetic: identical bits."""
+    n = 1500
+    x, g = _x(n, 2, 3), np.random.RandomState(4).standard_normal(n)
+    hyp = [1.0, 10.0, 1.2]
+    vals = []
+    gpmc = gp['gpmc']
+    try:
+        for la, gr, nb in ((1, 1, 256), (0, 1, 256), (1, 0, 256), (0, 0, 128), (1, 1, 512)):
+            gpmc.set_option('lookahead', la), gpmc.set_option('use_graph', gr), gpmc.set_option('outer_nb', nb)
+            plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+            vals.append([plan(hyp) for _ in range(3)])
+            plan.close()
+    finally:
+        gpmc.set_option('lookahead', 1), gpmc.set_option('use_graph', 1), gpmc.set_option('outer_nb', 256)
+    ref = sds_ref.gp_log_marginal(x, g, hyp)
+    for v in vals:
+        assert v[0] == v[1] == v[2]
+        assert abs(v[0] - ref) <= 1e-10 * abs(ref)
+    assert vals[0][0] == vals[1][0] == vals[2][0]          # same blocking, different schedule: bitwise equal
+
+
+def test_log_marginal_reports_not_pd(gp):
+    x = np.zeros((64, 1))                                  # all points coincide: K = sf2 * ones, S tiny
+    plan = gp['core'].LogMarginalPlan(x, np.ones(64), 'rbf')
+    plan.eval_async([1.0, 1.0, 1e-12])
+    assert plan.result()[3] != 0
+    with pytest.raises(np.linalg.LinAlgError):
+        plan([1.0, 1.0, 1e-12])
+    plan.close()
+
+
+def test_log_marginal_f32_matern(gp):
+    """config-5 shape at reduced N: fp32 ARD Matern; tolerance 1e-4 relative (fp32 factorisation, f64 reduction)."""
+    n, d = 1024, 8
+    x = _x(n, d, 21)
+    ell = np.random.RandomState(2).uniform(0.5, 2.0, d)
+    hyp = np.concatenate([ell * 3.0, [2.0, 0.5]])
+    g = np.random.RandomState(5).standard_normal(n)
+    ref = sds_ref.gp_log_marginal(x, g, hyp, kernel='matern52ard')
+    got = gp['core'].log_marginal(x, g, hyp, kernel='matern52ard', dtype=torch.float32)
+    assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
