@@ -37,6 +37,7 @@ struct Options {
     int lookahead = 1;    // factor panel k+1 on a second stream while the trailing update of k runs
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
+    int diag_impl = 1;        // 0: LDS column loop (v1), 1: single-wave register/MFMA factor
 };
 extern Options g_opt;
 
@@ -57,8 +58,10 @@ struct Mfma<double> {
     __device__ static inline acc_t mma(double a, double b, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
-    // row of accumulator register e for lane-quarter q
-    __device__ static inline int crow(int q, int e) { return q + 4 * e; }
+    // row of accumulator register e for lane-quarter q, and its inverse (row i lives in quarter rq(i), register re(i))
+    __host__ __device__ static constexpr int crow(int q, int e) { return q + 4 * e; }
+    __host__ __device__ static constexpr int rq(int i) { return i & 3; }
+    __host__ __device__ static constexpr int re(int i) { return i >> 2; }
 };
 // v_mfma_f32_16x16x4_f32: same A/B maps, D: col=l&15, row=4*(l>>4)+reg.
 template <>
@@ -69,7 +72,9 @@ struct Mfma<float> {
     __device__ static inline acc_t mma(float a, float b, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
-    __device__ static inline int crow(int q, int e) { return 4 * q + e; }
+    __host__ __device__ static constexpr int crow(int q, int e) { return 4 * q + e; }
+    __host__ __device__ static constexpr int rq(int i) { return i >> 2; }
+    __host__ __device__ static constexpr int re(int i) { return i & 3; }
 };
 
 template <typename T>

@@ -95,6 +95,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "lookahead")) g_opt.lookahead = value ? 1 : 0;
     else if (!strcmp(name, "use_graph")) g_opt.use_graph = value ? 1 : 0;
     else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
+    else if (!strcmp(name, "diag_impl")) g_opt.diag_impl = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -104,6 +105,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "lookahead")) return g_opt.lookahead;
     if (!strcmp(name, "use_graph")) return g_opt.use_graph;
     if (!strcmp(name, "small_tile_m")) return g_opt.small_tile_m;
+    if (!strcmp(name, "diag_impl")) return g_opt.diag_impl;
     return -1;
 }
 
@@ -219,7 +221,7 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     }
     GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)nk * p->es, hipMemcpyHostToDevice, p->stream));
     int rc = 0;
-    if (!g_opt.use_graph || p->evals == 0) {
+    if (!g_opt.use_graph || p->evals == 0 || p->stream == nullptr) {  // the NULL stream cannot be captured
         rc = plan_enqueue(p, p->stream);  // first evaluation runs eagerly (creates streams, sets attributes)
     } else {
         if (!p->exec) {

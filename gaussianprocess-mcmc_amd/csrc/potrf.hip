@@ -18,6 +18,7 @@
 // With look-ahead the panel of step k+1 is factored on a second stream while the rest of the
 // trailing update of step k runs.
 #include "gpmc_common.h"
+#include "diag_wave.h"
 
 namespace gpmc {
 
@@ -351,7 +352,10 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
             if (rc) return rc;
         }
         T* Wd = W + (size_t)c0 * ld + c0;
-        hipLaunchKernelGGL((diag_factor_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
+        if (g_opt.diag_impl == 0)
+            hipLaunchKernelGGL((diag_factor_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
+        else
+            hipLaunchKernelGGL((diag_factor_wave_kernel<T>), dim3(1), dim3(64), 0, s, Wd, ld, dinv, info_dev, c0);
         GPMC_LAUNCH_CHECK();
         const int below = mp - c0 - NB_IN;
         if (below > 0) {

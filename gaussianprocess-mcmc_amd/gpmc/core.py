@@ -32,7 +32,9 @@ class LogMarginalPlan(object):
         if nbytes == 0:
             raise _lib.GpmcError('gpmc_plan_workspace_bytes rejected n=%d d=%d' % (self.n, self.d))
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.X.device)  # caller-owned memory
-        self._stream = torch.cuda.current_stream()
+        # a stream of the plan's own: the legacy NULL stream torch starts on cannot be graph-captured
+        self._stream = torch.cuda.Stream(device=self.X.device)
+        self._stream.wait_stream(torch.cuda.current_stream())
         h = ctypes.c_void_p()
         _lib.check(L.gpmc_plan_create(ctypes.byref(h), ops.KERNELS[kernel], self.n, self.d, _ES[dtype],
                                       self.workspace.data_ptr(), nbytes, self._stream.cuda_stream), 'gpmc_plan_create')
@@ -42,6 +44,7 @@ class LogMarginalPlan(object):
 
     def set_g(self, g):
         self.g = ops.to_dev(g, self.dtype).reshape(-1)
+        self._stream.wait_stream(torch.cuda.current_stream())
         _lib.check(_lib.lib().gpmc_plan_set_data(self._h, self.X.data_ptr(), self.X.stride(0), self.g.data_ptr()),
                    'gpmc_plan_set_data')
 

@@ -25,7 +25,21 @@ def time_plan(plan, hyps, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def one(n, reps=5):
+    rng = np.random.RandomState(124)
+    X = rng.uniform(0, 10, (n, 2))
+    g = rng.standard_normal(n) * 5
+    plan = core.LogMarginalPlan(X, g, 'rbf')
+    dt = time_plan(plan, [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0]], reps)
+    print('n=%d default options: %.3f ms/eval' % (n, dt * 1e3), flush=True)
+    plan.close()
+
+
 def main():
+    if sys.argv[1:2] == ['--one']:
+        for a in sys.argv[2:]:
+            one(int(a))
+        return
     sizes = [int(a) for a in sys.argv[1:]] or [2048, 4096, 8192]
     rng = np.random.RandomState(124)
     hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [0.7, 12.0, 1.5], [3.0, 5.0, 2.0]]

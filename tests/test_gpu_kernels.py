@@ -20,6 +20,18 @@ def gp():
     return dict(gpmc=gpmc, core=core, covK=covK, ops=ops, tools=tools)
 
 
+def _assert_cov_close(K, Kref, sf2, ulps=16.0):
+    """fp64 kernel entries: |err| <= (ulps + 8|arg|) eps |Kref|, arg = log(Kref/sf2).  exp() turns an absolute
+    argument error into a relative one, and summing d squared differences in another order (FMA on the GPU,
+    mul+add in cdist) moves the argument by a few ulp of |arg|."""
+    eps = np.finfo(np.float64).eps
+    with np.errstate(divide='ignore'):
+        arg = np.abs(np.log(np.maximum(Kref, 1e-300) / sf2))
+    tol = (ulps + 8.0 * arg) * eps * np.abs(Kref) + 1e-300
+    bad = np.abs(K - Kref) > tol
+    assert not bad.any(), (int(bad.sum()), float(np.abs(K - Kref)[bad].max()))
+
+
 def _x(n, d, seed=0):
     return np.random.RandomState(seed).uniform(0., 10., (n, d))
 
@@ -39,19 +51,19 @@ def test_kbuild_rbf_train(gp, n, d):
     K = gp['covK'].RBF(np.log(ll), np.log(sf)).getCovMatrix(x=x, mode='train').cpu().numpy()
     Kref = ocovK.RBF(np.log(ll), np.log(sf)).getCovMatrix(x=x, mode='train')
     assert K.shape == (n, n)
-    np.testing.assert_allclose(K, Kref, rtol=2e-14, atol=1e-300)      # fp64: a few ulp of exp()
+    _assert_cov_close(K, Kref, sf ** 2)
 
 
 def test_kbuild_cross_selftest_and_diag(gp):
     x, z = _x(300, 2, 1), _x(77, 2, 2)
     k = gp['covK'].RBF(np.log(0.7), np.log(3.0))
     ko = ocovK.RBF(np.log(0.7), np.log(3.0))
-    np.testing.assert_allclose(k.getCovMatrix(x=x, z=z, mode='cross').cpu().numpy(),
-                               ko.getCovMatrix(x=x, z=z, mode='cross'), rtol=2e-14)
+    _assert_cov_close(k.getCovMatrix(x=x, z=z, mode='cross').cpu().numpy(), ko.getCovMatrix(x=x, z=z, mode='cross'), 9.0)
     np.testing.assert_allclose(k.getCovMatrix(z=z, mode='self_test').cpu().numpy(),
                                ko.getCovMatrix(z=z, mode='self_test'), rtol=1e-15)
     Kd = k.getCovMatrix(x=x, mode='train', diag_add=1.44).cpu().numpy()
-    np.testing.assert_allclose(Kd, ko.getCovMatrix(x=x, mode='train') + 1.44 * np.eye(300), rtol=2e-14)
+    Kr = ko.getCovMatrix(x=x, mode='train')
+    _assert_cov_close(Kd, Kr + 1.44 * np.eye(300), 9.0, ulps=32.0)
 
 
 @pytest.mark.parametrize('n,d', [(64, 1), (200, 8), (333, 3)])
@@ -60,7 +72,7 @@ def test_kbuild_matern_ard(gp, n, d):
     le = np.log(np.random.RandomState(3).uniform(0.5, 2.0, d))
     K = gp['covK'].MaternARD52(le, np.log(2.0)).getCovMatrix(x=x, mode='train').cpu().numpy()
     Kref = ocovK.MaternARD52(le, np.log(2.0)).getCovMatrix(x=x, mode='train')
-    np.testing.assert_allclose(K, Kref, rtol=1e-13, atol=1e-300)
+    _assert_cov_close(K, Kref, 4.0, ulps=32.0)
 
 
 def test_kbuild_f32(gp):
