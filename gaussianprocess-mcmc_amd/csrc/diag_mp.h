@@ -1,0 +1,160 @@
+// diag_mp.h -- 64x64 Cholesky by one 256-thread workgroup: 8-column micro-panels + v_mfma_f64_4x4x4 updates.
+//
+// FP64 VALU instructions cost ~9 cycles per wave-instruction at one wave per SIMD, so any scheme that
+// applies the rank-1 updates on the VALU spends ~1000 cycles per column.  Here the block lives in MFMA
+// accumulators as 4x16 "slabs" (lane (i = l>>4, c = l&15) of slab (g,h) = element [4g+i][16h+c], which
+// is both the D layout of v_mfma_f64_4x4x4_4b_f64 and one register of the 16x16x4 accumulator layout);
+// wave w owns slab rows g = w, w+4, w+8, w+12 (10 lower slabs).  Per micro-step t (columns 8t..8t+7):
+//   1. the owners copy those 8 columns (rows >= 8t) into LDS,
+//   2. wave 0 factors the 64x8 micro-panel with lane = row: pivots by v_readlane, 1/sqrt by v_rsq_f64 +
+//      two Goldschmidt steps, <= 7 FMAs per column; writes the columns of L into LDS,
+//   3. all waves apply the rank-8 update to their slabs straight from those columns: 2 MFMAs (16 cycles
+//      each) per slab.  MFMA operand maps (measured, scripts/mfma_probe.hip):
+//      A[i][k] lane 16k+4blk+i, B[k][j] lane 16k+4blk+j, D[i][j] lane 16i+4blk+j.
+// f64 only (the f32 path keeps the generic kernels).
+#pragma once
+#include "gpmc_common.h"
+
+namespace gpmc {
+
+constexpr int MP_LD = 66;   // Lout row stride (doubles)
+constexpr int MP_PLD = 9;   // micro-panel row stride (doubles)
+
+__device__ inline double mp_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt(d) and 1/sqrt(d): v_rsq_f64 seed + 2 Goldschmidt iterations (no division, no denormal fix-up path)
+__device__ inline void mp_sqrt_rsqrt(double d, double& sq, double& rs) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    sq = g;
+    rs = h + h;
+}
+
+// Slabs of wave w: D[m][h], m = 0..3 (slab row g = w + 4m), h = 0..m.
+// One micro-step, T8 compile-time.  All 256 threads call; two barriers inside.
+template <int T8>
+__device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
+                                     int w, int lane, int gcol) {
+    constexpr int HT = T8 >> 1;            // slab column that holds columns 8T8..8T8+7
+    constexpr int CLO = 8 * (T8 & 1);      // first lane-column of the micro-panel inside that slab
+    const int i = lane >> 4, c = lane & 15;
+    // ---- 1. extract columns 8T8..8T8+7, rows >= 8T8
+#pragma unroll
+    for (int m = HT; m < 4; ++m) {
+        const int g = w + 4 * m;
+        if (4 * g + 3 >= 8 * T8 && (c >> 3) == (T8 & 1)) Praw[4 * g + i][c - CLO] = D[m][HT];
+    }
+    __syncthreads();
+    // ---- 2. wave 0: factor the micro-panel, lane = row
+    if (w == 0) {
+        const int row = lane;
+        double p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = Praw[row][k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pr = 8 * T8 + k;                       // pivot row == pivot column
+            const double d = mp_readlane(p[k], pr);
+            if (!(d > 0.0) && lane == 0 && *failp == 0) *failp = gcol + pr + 1;
+            double sq, rs;
+            mp_sqrt_rsqrt(d, sq, rs);
+            double lk = p[k] * rs;
+            lk = (row == pr) ? sq : lk;
+            lk = (row < pr) ? 0.0 : lk;
+            p[k] = lk;
+#pragma unroll
+            for (int k2 = k + 1; k2 < 8; ++k2) {
+                const double mlt = mp_readlane(lk, 8 * T8 + k2);   // L[8T8+k2][8T8+k]
+                p[k2] = __builtin_fma(-lk, mlt, p[k2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Lout[row][8 * T8 + k] = p[k];
+    }
+    __syncthreads();
+    // ---- 3. rank-8 update of the slabs below / right of the micro-panel
+    if (T8 < 7) {
+        const int ka = lane >> 4, ia = lane & 3;             // A operand: lane (k, blk, i)
+        constexpr int HLO = (T8 + 1) >> 1;                   // first slab column with columns >= 8T8+8
+#pragma unroll
+        for (int m = HLO; m < 4; ++m) {
+            const int g = w + 4 * m;
+            if (g >= 2 * T8 + 2) {
+                const double a0 = -Lout[4 * g + ia][8 * T8 + ka];
+                const double a1 = -Lout[4 * g + ia][8 * T8 + 4 + ka];
+#pragma unroll
+                for (int h = HLO; h <= m; ++h) {
+                    const bool live = 16 * h + c >= 8 * T8 + 8;           // finished columns must not move
+                    const double b0 = live ? Lout[16 * h + c][8 * T8 + i] : 0.0;   // B operand: lane (k = l>>4, col)
+                    const double b1 = live ? Lout[16 * h + c][8 * T8 + 4 + i] : 0.0;
+                    D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, D[m][h], 0, 0, 0);
+                    D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, D[m][h], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// Factor the block held in slabs; on return Lout holds L (strict upper zero).  gcol = global column of the block.
+__device__ inline void mp_factor64(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
+                                   int tid, int gcol) {
+    const int w = tid >> 6, lane = tid & 63;
+    if (tid == 0) *failp = 0;
+    __syncthreads();
+    mp_micro_step<0>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<1>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<2>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<3>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<4>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<5>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<6>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<7>(D, Lout, Praw, failp, w, lane, gcol);
+    __syncthreads();
+}
+
+// Standalone launch (drop-in for the other diag kernels): also emits the 16x16 inverse tiles trsm_strip uses.
+__global__ void __launch_bounds__(256)
+diag_factor_mp_kernel(double* __restrict__ Wd, int ld, double* __restrict__ dinv, int* __restrict__ info, int c0) {
+    __shared__ double Lout[64][MP_LD];
+    __shared__ double Praw[64][MP_PLD];
+    __shared__ int sfail;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int i = lane >> 4, c = lane & 15;
+    double D[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            D[m][h] = (h <= m) ? Wd[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
+    mp_factor64(D, Lout, Praw, &sfail, tid, c0);
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, cc = e & 63;
+        Wd[(size_t)r * ld + cc] = Lout[r][cc];
+    }
+    if (tid < 64) {  // inverse of diagonal tile t, column jj, by forward substitution
+        const int t = tid >> 4, jj = tid & 15, o = 16 * t;
+        double x[16];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            double s = (ii == jj) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < ii; ++k) s -= Lout[o + ii][o + k] * x[k];
+            x[ii] = s / Lout[o + ii][o + ii];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) dinv[t * 256 + ii * 16 + jj] = x[ii];
+    }
+    if (tid == 0 && sfail != 0) atomicCAS(info, 0, sfail);
+}
+
+}  // namespace gpmc

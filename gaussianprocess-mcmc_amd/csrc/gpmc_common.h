@@ -37,7 +37,8 @@ struct Options {
     int lookahead = 1;    // factor panel k+1 on a second stream while the trailing update of k runs
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
-    int diag_impl = 1;        // 0: LDS column loop (v1), 1: single-wave register/MFMA factor
+    int panel_impl = 1;       // 1: fused update+factor+TRSM kernel per 64 columns (f64), 0: three kernels
+    int diag_impl = 3;        // 0: LDS column loop, 1: single wave, 2: register-blocked VALU, 3: micro-panel + MFMA 4x4x4
 };
 extern Options g_opt;
 

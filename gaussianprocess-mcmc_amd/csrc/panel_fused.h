@@ -1,0 +1,188 @@
+// panel_fused.h -- one kernel per 64-column block of the outer panel (f64): left-looking update,
+// diagonal factor and TRSM fused, everything on v_mfma_f64_4x4x4_4b_f64.
+//
+// Grid: one 256-thread workgroup per 64-row strip from the diagonal block down (strip 0 = the diagonal
+// block itself).  Every workgroup
+//   1. accumulates  P_D = L_d L_d^T  (lower slabs of the diagonal block, K = c0-k0 columns of this outer
+//      panel already factored) and  P_T = L_d L_s^T  (its own strip, TRANSPOSED: slab rows = block
+//      columns, lanes = strip rows) from 64-column chunks staged in LDS;
+//   2. factors D = A_dd - P_D REDUNDANTLY (diag_mp.h) -- recomputing a 64x64 factor in every workgroup
+//      costs no wall time and removes two kernel boundaries and the 16x16 inverse tiles;
+//   3. solves its strip: Y = T^T-form forward substitution by 4-row slabs with the 4x4 diagonal
+//      inverses, Y_p = inv(L_pp) T_p ; T_g -= L_gp Y_p -- an accumulator slab is the next MFMA's B
+//      operand unchanged;
+//   4. writes the strip back through an LDS transpose.  Strip 0 must NOT overwrite the diagonal block
+//      in place -- slower workgroups of the same launch still read it as input -- so it parks L in
+//      scratch and the NEXT launch on the stream (or panel_flush_kernel at the end) copies it into W.
+#pragma once
+#include "diag_mp.h"
+
+namespace gpmc {
+
+struct PanelShared {
+    double Ld[64][MP_LD];     // chunk of the diagonal strip's rows, [row][k]
+    double Ls[64][MP_LD];     // chunk of this strip's rows; later the strip block in / out
+    double Lout[64][MP_LD];   // the diagonal block's factor
+    double Praw[64][MP_PLD];
+    double Linv[16][4][4];    // inverses of the 4x4 diagonal blocks of Lout
+    int fail;
+};
+
+__global__ void __launch_bounds__(256)
+panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
+                   double* __restrict__ lpark, int prev_c0) {
+    extern __shared__ __attribute__((aligned(16))) char panel_smem[];
+    PanelShared& sh = *reinterpret_cast<PanelShared*>(panel_smem);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int i = lane >> 4, c = lane & 15, ia = lane & 3;   // i doubles as the operands' k index (lane >> 4)
+    const bool is_diag = (blockIdx.x == 0);
+    const size_t R0 = (size_t)c0 + 64 * (size_t)blockIdx.x;
+
+    if (is_diag && prev_c0 >= 0) {   // flush the previous block's factor (nobody reads that block in this launch)
+        const double* src = lpark + (size_t)(prev_c0 / 64) * 4096;
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&W[((size_t)prev_c0 + row) * ld + prev_c0 + c2]) =
+                *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]);
+        }
+    }
+    double PD[4][4];
+    double PT[16];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) PD[m][h] = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) PT[g] = 0.0;
+
+    // ---------------- 1. left-looking products over the K = c0 - k0 finished columns of this outer panel
+    for (int kc = k0; kc < c0; kc += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&sh.Ld[row][c2]) =
+                *reinterpret_cast<const d2_t*>(&W[((size_t)c0 + row) * ld + kc + c2]);
+            if (!is_diag)
+                *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) =
+                    *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + kc + c2]);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int ko = 8 * k8 + 2 * i;   // this lane's k pair
+            d2_t bD[4], aD[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ld[16 * h + c][ko]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (w + 4 * m) + ia][ko]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int h = 0; h <= m; ++h) {
+                    PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][0], bD[h][0], PD[m][h], 0, 0, 0);
+                    PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][1], bD[h][1], PD[m][h], 0, 0, 0);
+                }
+            if (!is_diag) {
+                const d2_t bT = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const d2_t aT = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * g + ia][ko]);
+                    PT[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[0], bT[0], PT[g], 0, 0, 0);
+                    PT[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[1], bT[1], PT[g], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---------------- D = A_dd - P_D (slab layout straight from global: 4 rows x 128 B per load)
+    double D[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            D[m][h] = (h <= m) ? W[((size_t)c0 + 4 * (w + 4 * m) + i) * ld + c0 + 16 * h + c] - PD[m][h] : 0.0;
+
+    // ---------------- T = (A_sd - P)^T : the strip block goes through LDS to be read transposed
+    double T[16];
+    if (!is_diag) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) =
+                *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + c0 + c2]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 16; ++g) T[g] = sh.Ls[16 * w + c][4 * g + i] - PT[g];
+    }
+
+    // ---------------- 2. factor the diagonal block (every workgroup)
+    mp_factor64(D, sh.Lout, sh.Praw, &sh.fail, tid, c0);
+
+    if (is_diag) {
+        double* dst = lpark + (size_t)(c0 / 64) * 4096;
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&dst[row * 64 + c2]) = *reinterpret_cast<const d2_t*>(&sh.Lout[row][c2]);
+        }
+        if (tid == 0 && sh.fail != 0) atomicCAS(info, 0, sh.fail);
+        return;
+    }
+
+    // ---------------- 2.5 inverses of the sixteen 4x4 diagonal blocks
+    if (tid < 16) {
+        const int o = 4 * tid;
+        const double l00 = sh.Lout[o][o], l10 = sh.Lout[o + 1][o], l11 = sh.Lout[o + 1][o + 1];
+        const double l20 = sh.Lout[o + 2][o], l21 = sh.Lout[o + 2][o + 1], l22 = sh.Lout[o + 2][o + 2];
+        const double l30 = sh.Lout[o + 3][o], l31 = sh.Lout[o + 3][o + 1], l32 = sh.Lout[o + 3][o + 2],
+                     l33 = sh.Lout[o + 3][o + 3];
+        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22, i33 = 1.0 / l33;
+        const double i10 = -(l10 * i00) * i11;
+        const double i21 = -(l21 * i11) * i22;
+        const double i32 = -(l32 * i22) * i33;
+        const double i20 = -(l20 * i00 + l21 * i10) * i22;
+        const double i31 = -(l31 * i11 + l32 * i21) * i33;
+        const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
+        double(*V)[4] = sh.Linv[tid];
+        V[0][0] = i00; V[0][1] = 0.0; V[0][2] = 0.0; V[0][3] = 0.0;
+        V[1][0] = i10; V[1][1] = i11; V[1][2] = 0.0; V[1][3] = 0.0;
+        V[2][0] = i20; V[2][1] = i21; V[2][2] = i22; V[2][3] = 0.0;
+        V[3][0] = i30; V[3][1] = i31; V[3][2] = i32; V[3][3] = i33;
+    }
+    __syncthreads();
+
+    // ---------------- 3. TRSM: wave w solves its 16 strip rows (lanes c), 4-row slabs p = 0..15
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const double av = sh.Linv[p][ia][i];                       // A[i][k] = inv(L_pp)[i][k], lane (k, blk, i)
+        const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T[p], 0.0, 0, 0, 0);
+        T[p] = Y;
+#pragma unroll
+        for (int g = p + 1; g < 16; ++g) {
+            const double al = -sh.Lout[4 * g + ia][4 * p + i];     // A[i][k] = -L[4g+i][4p+k]
+            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
+        }
+    }
+
+    // ---------------- 4. write the strip back (transpose through LDS, then 512-B row segments)
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = T[g];
+    __syncthreads();
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int row = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<d2_t*>(&W[(R0 + row) * ld + c0 + c2]) = *reinterpret_cast<const d2_t*>(&sh.Ls[row][c2]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+panel_flush_kernel(double* __restrict__ W, int ld, const double* __restrict__ lpark, int c0) {
+    const double* src = lpark + (size_t)(c0 / 64) * 4096;
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int row = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<d2_t*>(&W[((size_t)c0 + row) * ld + c0 + c2]) =
+            *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]);
+    }
+}
+
+}  // namespace gpmc

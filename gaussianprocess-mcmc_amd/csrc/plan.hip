@@ -34,7 +34,7 @@ static PlanLayout plan_layout(int n, int d, int es) {
     L.off_hyp = take((size_t)(2 + PLAN_MAXD) * es);
     L.off_out = take(4 * sizeof(double));
     L.off_info = take(sizeof(int));
-    L.off_scratch = take((size_t)(L.np_ / NB_IN) * 1024 * es);
+    L.off_scratch = take((size_t)(L.np_ / NB_IN + 1) * (1024 + 4096) * sizeof(double));
     L.total = o;
     return L;
 }
@@ -87,7 +87,7 @@ extern "C" {
 int gpmc_version(void) { return GPMC_VERSION; }
 const char* gpmc_last_error(void) { return g_err; }
 int gpmc_pad(int n) { return round_up(n, GPMC_PAD); }
-size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double); }
+size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096) * sizeof(double); }
 
 int gpmc_set_option(const char* name, int value) {
     if (!name) return fail(-1, "gpmc_set_option: null name");
@@ -96,6 +96,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "use_graph")) g_opt.use_graph = value ? 1 : 0;
     else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
     else if (!strcmp(name, "diag_impl")) g_opt.diag_impl = value;
+    else if (!strcmp(name, "panel_impl")) g_opt.panel_impl = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -106,6 +107,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "use_graph")) return g_opt.use_graph;
     if (!strcmp(name, "small_tile_m")) return g_opt.small_tile_m;
     if (!strcmp(name, "diag_impl")) return g_opt.diag_impl;
+    if (!strcmp(name, "panel_impl")) return g_opt.panel_impl;
     return -1;
 }
 
@@ -191,7 +193,7 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     // zero the riding rows once: only row np_ is ever rewritten (with g), the others stay zero
     e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
                        (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
-    if (e != hipSuccess) { hipHostFree(p->host_pin); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipHostFree(p->host_pin); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
     *out = p;
     return 0;
 }
@@ -262,10 +264,10 @@ int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld) {
 
 int gpmc_plan_destroy(gpmc_plan* p) {
     if (!p) return 0;
-    hipStreamSynchronize(p->stream);
-    if (p->exec) hipGraphExecDestroy(p->exec);
-    if (p->graph) hipGraphDestroy(p->graph);
-    if (p->host_pin) hipHostFree(p->host_pin);
+    (void)hipStreamSynchronize(p->stream);
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->host_pin) (void)hipHostFree(p->host_pin);
     delete p;
     return 0;
 }

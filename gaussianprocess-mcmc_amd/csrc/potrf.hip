@@ -19,6 +19,9 @@
 // trailing update of step k runs.
 #include "gpmc_common.h"
 #include "diag_wave.h"
+#include "diag_rb.h"
+#include "diag_mp.h"
+#include "panel_fused.h"
 
 namespace gpmc {
 
@@ -342,7 +345,21 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
 
 // factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks
 template <typename T>
-static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, hipStream_t s) {
+static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s) {
+    if (sizeof(T) == 8 && g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns
+        static bool attr_done = false;
+        if (!attr_done) {
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
+            attr_done = true;
+        }
+        for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
+            hipLaunchKernelGGL(panel_block_kernel, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
+                               reinterpret_cast<double*>(W), ld, k0, c0, info_dev, lpark, c0 - NB_IN);
+            GPMC_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
         if (c0 > k0) {  // rows [c0, mp) x cols [c0, c0+64) -= L[rows, k0:c0] L[c0:c0+64, k0:c0]^T
             const T* Ap = W + (size_t)c0 * ld + k0;
@@ -354,8 +371,13 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
         T* Wd = W + (size_t)c0 * ld + c0;
         if (g_opt.diag_impl == 0)
             hipLaunchKernelGGL((diag_factor_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
-        else
+        else if (g_opt.diag_impl == 1)
             hipLaunchKernelGGL((diag_factor_wave_kernel<T>), dim3(1), dim3(64), 0, s, Wd, ld, dinv, info_dev, c0);
+        else if (g_opt.diag_impl == 2 || sizeof(T) != 8)
+            hipLaunchKernelGGL((diag_factor_rb_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
+        else
+            hipLaunchKernelGGL(diag_factor_mp_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<double*>(Wd), ld,
+                               reinterpret_cast<double*>(dinv), info_dev, c0);
         GPMC_LAUNCH_CHECK();
         const int below = mp - c0 - NB_IN;
         if (below > 0) {
@@ -378,6 +400,15 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(scratch != nullptr, 6);
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
     T* dinv = reinterpret_cast<T*>(scratch);
+    double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
+    const bool fused = (sizeof(T) == 8 && g_opt.panel_impl == 1);
+    auto final_flush = [&]() -> int {
+        if (!fused) return 0;
+        hipLaunchKernelGGL(panel_flush_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<double*>(W), ldw, lpark,
+                           np_ - NB_IN);
+        GPMC_LAUNCH_CHECK();
+        return 0;
+    };
     int NB = g_opt.outer_nb;
     if (NB < 128 || NB % 128) NB = 256;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
@@ -385,7 +416,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     if (!g_opt.lookahead || np_ <= NB) {
         for (int k0 = 0; k0 < np_; k0 += NB) {
             const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
-            int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, s);
+            int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
             if (rc) return rc;
             const int k1 = k0 + nbk;
             if (k1 < np_) {
@@ -393,7 +424,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
             }
         }
-        return 0;
+        return final_flush();
     }
 
     // ---- look-ahead: after panel k, update only the next panel's columns first (on s), then factor
@@ -409,7 +440,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // panel 0 on the main stream
     {
         const int nbk = (np_ < NB) ? np_ : NB;
-        int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, s);
+        int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, lpark, s);
         if (rc) return rc;
     }
     for (int k0 = 0; k0 < np_; k0 += NB) {
@@ -424,7 +455,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         GPMC_HIP(hipEventRecord(e1, s));
         // (2) factor next panel on ps
         GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
-        rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, ps);
+        rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
         if (rc) return rc;
         hipEvent_t e2 = next_ev();
         GPMC_HIP(hipEventRecord(e2, ps));
@@ -435,7 +466,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         }
         GPMC_HIP(hipStreamWaitEvent(s, e2, 0));
     }
-    return 0;
+    return final_flush();
 }
 
 template <typename T>

@@ -36,6 +36,13 @@ def one(n, reps=5):
 
 
 def main():
+    if sys.argv[1:2] == ['--diag']:
+        for impl in (1, 2, 3):
+            gpmc.set_option('diag_impl', impl)
+            print('diag_impl', impl)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--one']:
         for a in sys.argv[2:]:
             one(int(a))
