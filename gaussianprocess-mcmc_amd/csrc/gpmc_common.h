@@ -33,8 +33,9 @@ inline int fail(int code, const char* fmt, ...) {
 
 // ---------------------------------------------------------------- options
 struct Options {
-    int outer_nb = 256;   // outer block of the right-looking Cholesky (multiple of 128)
-    int lookahead = 1;    // factor panel k+1 on a second stream while the trailing update of k runs
+    int outer_nb = 128;   // outer block of the right-looking Cholesky (multiple of 128)
+    int lookahead = 0;    // factor panel k+1 on a second stream while the trailing update of k runs (measured: no gain,
+                          // both kernels want every CU's LDS/VGPRs; kept as an option)
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
     int panel_impl = 1;       // 1: fused update+factor+TRSM kernel per 64 columns (f64), 0: three kernels

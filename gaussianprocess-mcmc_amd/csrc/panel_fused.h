@@ -20,9 +20,11 @@
 namespace gpmc {
 
 struct PanelShared {
-    double Ld[64][MP_LD];     // chunk of the diagonal strip's rows, [row][k]
+    // Ld: chunk of the diagonal strip's rows [row][k] (phase 1); the SAME storage then holds the diagonal
+    // block's factor Lout (phases 2-3) -- 74 KB in all, so a panel workgroup fits on a CU beside one
+    // 74 KB GEMM workgroup and the look-ahead really overlaps.
+    double Ld[64][MP_LD];
     double Ls[64][MP_LD];     // chunk of this strip's rows; later the strip block in / out
-    double Lout[64][MP_LD];   // the diagonal block's factor
     double Praw[64][MP_PLD];
     double Linv[16][4][4];    // inverses of the 4x4 diagonal blocks of Lout
     int fail;
@@ -33,6 +35,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
                    double* __restrict__ lpark, int prev_c0) {
     extern __shared__ __attribute__((aligned(16))) char panel_smem[];
     PanelShared& sh = *reinterpret_cast<PanelShared*>(panel_smem);
+    double (*Lout)[MP_LD] = sh.Ld;   // aliased: valid once phase 1 is over
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;   // i doubles as the operands' k index (lane >> 4)
     const bool is_diag = (blockIdx.x == 0);
@@ -116,14 +119,15 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         for (int g = 0; g < 16; ++g) T[g] = sh.Ls[16 * w + c][4 * g + i] - PT[g];
     }
 
-    // ---------------- 2. factor the diagonal block (every workgroup)
-    mp_factor64(D, sh.Lout, sh.Praw, &sh.fail, tid, c0);
+    // ---------------- 2. factor the diagonal block (every workgroup); Ld is dead from here on
+    __syncthreads();
+    mp_factor64(D, Lout, sh.Praw, &sh.fail, tid, c0);
 
     if (is_diag) {
         double* dst = lpark + (size_t)(c0 / 64) * 4096;
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&dst[row * 64 + c2]) = *reinterpret_cast<const d2_t*>(&sh.Lout[row][c2]);
+            *reinterpret_cast<d2_t*>(&dst[row * 64 + c2]) = *reinterpret_cast<const d2_t*>(&Lout[row][c2]);
         }
         if (tid == 0 && sh.fail != 0) atomicCAS(info, 0, sh.fail);
         return;
@@ -132,10 +136,10 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     // ---------------- 2.5 inverses of the sixteen 4x4 diagonal blocks
     if (tid < 16) {
         const int o = 4 * tid;
-        const double l00 = sh.Lout[o][o], l10 = sh.Lout[o + 1][o], l11 = sh.Lout[o + 1][o + 1];
-        const double l20 = sh.Lout[o + 2][o], l21 = sh.Lout[o + 2][o + 1], l22 = sh.Lout[o + 2][o + 2];
-        const double l30 = sh.Lout[o + 3][o], l31 = sh.Lout[o + 3][o + 1], l32 = sh.Lout[o + 3][o + 2],
-                     l33 = sh.Lout[o + 3][o + 3];
+        const double l00 = Lout[o][o], l10 = Lout[o + 1][o], l11 = Lout[o + 1][o + 1];
+        const double l20 = Lout[o + 2][o], l21 = Lout[o + 2][o + 1], l22 = Lout[o + 2][o + 2];
+        const double l30 = Lout[o + 3][o], l31 = Lout[o + 3][o + 1], l32 = Lout[o + 3][o + 2],
+                     l33 = Lout[o + 3][o + 3];
         const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22, i33 = 1.0 / l33;
         const double i10 = -(l10 * i00) * i11;
         const double i21 = -(l21 * i11) * i22;
@@ -159,7 +163,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         T[p] = Y;
 #pragma unroll
         for (int g = p + 1; g < 16; ++g) {
-            const double al = -sh.Lout[4 * g + ia][4 * p + i];     // A[i][k] = -L[4g+i][4p+k]
+            const double al = -Lout[4 * g + ia][4 * p + i];     // A[i][k] = -L[4g+i][4p+k]
             T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
         }
     }

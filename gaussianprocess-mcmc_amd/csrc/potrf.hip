@@ -332,13 +332,14 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
 
 // C(mrows x ncols region) -= A A_j^T, big (128x128) or small (64x64) tiles by problem size
 template <typename T>
-static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi) {
+static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi,
+                           bool latency_bound = false) {
     // update columns [col_lo, col_hi) of the trailing matrix (rows >= col_lo), K = nbk panel at k0
     const int rows = mp - col_lo;
     const int cols = col_hi - col_lo;
     const T* P = W + (size_t)col_lo * ld + k0;
     T* C = W + (size_t)col_lo * ld + col_lo;
-    if (rows > g_opt.small_tile_m)
+    if (rows > g_opt.small_tile_m && !latency_bound)
         return launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
     return launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
 }
@@ -449,7 +450,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (k1 >= np_) break;
         const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;  // next panel width
         // (1) next panel's columns, on s
-        int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn);
+        int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn, true);
         if (rc) return rc;
         hipEvent_t e1 = next_ev();
         GPMC_HIP(hipEventRecord(e1, s));

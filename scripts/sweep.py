@@ -43,6 +43,20 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--tiles']:
+        for stm, nb, la in ((3072, 256, 1), (100000, 256, 1), (100000, 128, 1), (100000, 512, 1), (100000, 256, 0), (100000, 128, 0)):
+            gpmc.set_option('small_tile_m', stm), gpmc.set_option('outer_nb', nb), gpmc.set_option('lookahead', la)
+            print('small_tile_m', stm, 'outer_nb', nb, 'lookahead', la)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
+    if sys.argv[1:2] == ['--graph']:
+        for gr in (0, 1):
+            gpmc.set_option('use_graph', gr)
+            print('use_graph', gr)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--one']:
         for a in sys.argv[2:]:
             one(int(a))
