@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- GP log-marginal evals/sec (= slice-sample steps/sec) on MI355X.
+
+One "step" = one evaluation of log N(g; 0, K(hyp) + S) at fresh hyper-parameters on the workload
+BASELINE.json's metric is quoted on: RBF kernel, N = 8192, d = 2, fp64, synthetic (X, g) resident in HBM
+(SURVEY.md 8(d)): K build + S diagonal + blocked Cholesky with g riding + reduction, scalar + info back to
+the host.  Evaluations are issued back to back on one stream with distinct hyper-parameters cycled from 16
+points drawn from the sampler's bracket; nothing is cached between steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--sds]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs its own independent chain-shaped
+stream of evaluations on its own GPU (weak scaling, no data-path collective); rank 0 prints ONE JSON line with
+the whole-job rate = total evaluations / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'gaussianprocess-mcmc_amd'))
+sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TF = 78.6      # AMD MI355X spec, FP64 matrix (= vector); measured instruction ceilings in DESIGN.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_inputs(n, d, seed=124, truth=(1.0, 10.0, 1.2), npoints=16, scale=(10., 10., 5.)):
+    """X ~ U(0,10)^(n x d); g ~ N(0, 25 I) stands in for the GP draw (the cost of an evaluation does not depend
+    on g); 16 hyper-parameter points from the sampler's bracket [max(h - U(0,s), 0), +s], floored at 0.05."""
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0., 10., (n, d))
+    g = rng.standard_normal(n) * 5.0
+    h, s = np.asarray(truth), np.asarray(scale)
+    pts = []
+    for _ in range(npoints):
+        lo = np.maximum(h - rng.uniform(0., s), 0.)
+        pts.append(np.maximum(rng.uniform(lo, lo + s), 0.05))
+    return X, g, np.asarray(pts)
+
+
+def cpu_baseline(X, g, pts, budget_s=20.0):
+    """B-lean of BASELINE.md: the oracle's SciPy path (cdist+exp, dpotrf, dtrsv) on the host cores, bounded sample."""
+    from oracle import sds_ref
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    vals, k = [], 0
+    while True:
+        vals.append(sds_ref.gp_log_marginal(X, g, pts[k % len(pts)]))
+        k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or k >= 8:
+            break
+    return dict(value=k / el, unit='evals/s', cores=int(threads), kind='port',
+                sample='%d evaluations of the same N=%d workload (first hyper-parameter points), %.1f s' % (k, X.shape[0], el)), vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--n', type=int, default=8192)
+    ap.add_argument('--d', type=int, default=2)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--sds', action='store_true', help='also time full SDS proposals (reported in the "extra" field)')
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gpmc
+    from gpmc import _lib, chains, core
+
+    rank, world = chains.init_distributed()
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the gpmc product path has no CPU fallback)')
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank)
+    # eager launches (about 190 per evaluation at N=8192, the host runs far ahead of the GPU) so that the
+    # dominant kernel can be bracketed by HIP events on its own stream inside the timed region
+    gpmc.set_option('use_graph', 0)
+    plan = core.LogMarginalPlan(X, g, 'rbf')
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        plan.eval_async(pts[i % len(pts)], i % 32)
+    plan.result((a.warmup - 1) % 32 if a.warmup else 0)
+
+    barrier()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        plan.eval_async(pts[i % len(pts)], i % 32)
+    last = plan.result((a.steps - 1) % 32)
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, k_launches, k_flops = _lib.profile_read()
+    if last[3] != 0:
+        raise SystemExit('factorisation reported info=%d' % last[3])
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+
+    # parity of the timed path against the oracle on this rank's first points (checker, outside the timed region)
+    cpu = None
+    if rank == 0 and not a.no_cpu:
+        cpu, vals = cpu_baseline(X, g, pts)
+        for j, v in enumerate(vals[:2]):
+            got = plan(pts[j])
+            if abs(got - v) > 1e-8 * abs(v):
+                raise SystemExit('parity failure vs SciPy at point %d: %r vs %r' % (j, got, v))
+
+    extra = {}
+    if a.sds and rank == 0:
+        from gpmc import sds
+        ws = sds.SDSWorkspace(X)
+        f = torch.zeros(a.n, dtype=torch.float64, device=dev)
+        gd = torch.as_tensor(g).to(dev)
+        ws.aux_var_model(f, pts[0], gd, need_eta=True)
+        eta = ws.eta.clone()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for j in range(reps):
+            ws.aux_var_model(f, pts[j % len(pts)], gd, need_eta=False)
+            ws.propose_f(eta).cpu()
+        torch.cuda.synchronize()
+        extra['sds_proposals_per_s'] = reps / (time.perf_counter() - t1)
+
+    if rank == 0:
+        value = world * a.steps / tmax
+        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            'metric': 'GP log-marginal evals/sec (= slice-sample steps/sec) at N=%d' % a.n,
+            'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * tmax / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
+                       'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
+                       'outer_nb': gpmc.get_option('outer_nb'), 'launch': 'eager'},
+            'roofline': {'bound': 'mfma', 'kernel': 'gpmc::gemm_nt_kernel (trailing SYRK update of the blocked Cholesky)',
+                         'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_MATRIX_PEAK_TF,
+                         'launches_per_step': k_launches / max(a.steps, 1),
+                         'avg_launch_us': 1e3 * k_ms / max(k_launches, 1),
+                         'algorithmic_flops_per_launch': k_flops / max(k_launches, 1),
+                         'whole_step_tflops': (a.n ** 3 / 3.0) / (tmax / a.steps) / 1e12,
+                         'traffic': None},
+            'cpu_baseline': cpu,
+        }
+        if extra:
+            line['extra'] = extra
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

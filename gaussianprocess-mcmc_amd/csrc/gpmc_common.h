@@ -121,5 +121,7 @@ struct Aux {
     bool ready = false;
 };
 int aux_get(Aux** out);
+int profile_begin();
+int profile_read(double* out);
 
 }  // namespace gpmc

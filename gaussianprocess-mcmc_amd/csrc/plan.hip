@@ -111,6 +111,12 @@ int gpmc_get_option(const char* name) {
     return -1;
 }
 
+int gpmc_profile_begin(void) { return profile_begin(); }
+int gpmc_profile_read(double* out3) {
+    if (!out3) return fail(-1, "gpmc_profile_read: null out");
+    return profile_read(out3);
+}
+
 #define S_(x) reinterpret_cast<hipStream_t>(x)
 
 int gpmc_kbuild_f64(int kernel, const double* X, int n, int d, int ldx, const double* Z, int nz, int ldz,

@@ -17,6 +17,8 @@
 //                      accumulator layout is exactly the B-operand layout, so no data movement)
 // With look-ahead the panel of step k+1 is factored on a second stream while the rest of the
 // trailing update of step k runs.
+#include <vector>
+
 #include "gpmc_common.h"
 #include "diag_wave.h"
 #include "diag_rb.h"
@@ -330,6 +332,47 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     return 0;
 }
 
+// ---- optional instrumentation of the dominant kernel (trailing SYRK update): HIP event pairs recorded on the
+// launch stream around every launch, summed by gpmc_profile_read().  Used by bench.py for the roofline line.
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+    double flops = 0.0;
+    long launches = 0;
+};
+static Prof g_prof;
+static int prof_mark(hipStream_t s) {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        GPMC_HIP(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+    }
+    GPMC_HIP(hipEventRecord(g_prof.ev[g_prof.used++], s));
+    return 0;
+}
+int profile_begin() {
+    g_prof.on = true;
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    g_prof.launches = 0;
+    return 0;
+}
+int profile_read(double* out) {   // out: [0] total ms in the kernel, [1] launches, [2] algorithmic flops
+    g_prof.on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        GPMC_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+        float t = 0.f;
+        GPMC_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+        ms += t;
+    }
+    out[0] = ms;
+    out[1] = (double)g_prof.launches;
+    out[2] = g_prof.flops;
+    return 0;
+}
+
 // C(mrows x ncols region) -= A A_j^T, big (128x128) or small (64x64) tiles by problem size
 template <typename T>
 static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi,
@@ -339,9 +382,24 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
     const int cols = col_hi - col_lo;
     const T* P = W + (size_t)col_lo * ld + k0;
     T* C = W + (size_t)col_lo * ld + col_lo;
+    if (g_prof.on) {
+        int rc = prof_mark(s);
+        if (rc) return rc;
+        // algorithmic flops: the lower triangle (incl. diagonal) of the cols x cols square part plus the
+        // (np_ - col_hi) x cols block below it inside the matrix; riding right-hand-side rows are not counted
+        const double sq = 0.5 * (double)cols * ((double)cols + 1.0);
+        const double below = (double)(np_ - col_hi) * (double)cols;
+        g_prof.flops += 2.0 * (double)nbk * (sq + below);
+        g_prof.launches++;
+    }
+    int rc;
     if (rows > g_opt.small_tile_m && !latency_bound)
-        return launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
-    return launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+        rc = launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+    else
+        rc = launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+    if (rc) return rc;
+    if (g_prof.on) return prof_mark(s);
+    return 0;
 }
 
 // factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks

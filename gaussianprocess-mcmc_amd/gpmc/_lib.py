@@ -61,6 +61,8 @@ def _sig(lib):
         'gpmc_plan_workspace': ([P, ctypes.POINTER(c_void_p), ctypes.POINTER(I), ctypes.POINTER(I),
                                  ctypes.POINTER(I)], I),
         'gpmc_plan_destroy': ([P], I),
+        'gpmc_profile_begin': ([], I),
+        'gpmc_profile_read': ([ctypes.POINTER(c_double)], I),
         'gpmc_set_option': ([c_char_p, I], I),
         'gpmc_get_option': ([c_char_p], I),
     }
@@ -99,6 +101,17 @@ def set_option(name, value):
 
 def get_option(name):
     return lib().gpmc_get_option(name.encode())
+
+
+def profile_begin():
+    check(lib().gpmc_profile_begin(), 'gpmc_profile_begin')
+
+
+def profile_read():
+    """(total_ms, launches, algorithmic_flops) of the trailing-update kernel since profile_begin()"""
+    out = (c_double * 3)()
+    check(lib().gpmc_profile_read(out), 'gpmc_profile_read')
+    return float(out[0]), int(out[1]), float(out[2])
 
 
 def pad(n):

@@ -1,0 +1,53 @@
+"""Chain-parallel multi-GPU driver: one process per GPU, one independent chain per rank,
+no data-path collective; exactly one gather of the chain histories at the end (RCCL over xGMI when the
+process group's backend is ``nccl``; ``gloo`` on CPU tensors in the tests)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 0, 1
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def gather_histories(histHyp, histF=None, device=None):
+    """all_gather per-rank histories -> (world, 3, iters) [, (world, n, iters)] ndarrays on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return (np.asarray(histHyp)[None], None if histF is None else np.asarray(histF)[None])
+    world = dist.get_world_size()
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else 'cpu'
+    out = []
+    for h in (histHyp, histF):
+        if h is None:
+            out.append(None)
+            continue
+        t = torch.as_tensor(np.ascontiguousarray(h), dtype=torch.float64).to(device)
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        out.append(torch.stack(bufs).cpu().numpy())
+    return out[0], out[1]
+
+
+def run_chains(x, y, iters, hyp0, seed_base=124, gather_f=False, chain_fn=None):
+    """Rank r runs chain r (legacy np.random seeded with seed_base + r) on its own GPU, then one gather."""
+    rank, world = init_distributed()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1))
+    np.random.seed(seed_base + rank)
+    if chain_fn is None:
+        from . import framework
+        chain_fn = framework.run_chain
+    histF, histHyp, ntries = chain_fn(x, y, iters, hyp0)
+    allHyp, allF = gather_histories(histHyp, histF if gather_f else None)
+    return dict(rank=rank, world=world, histHyp=allHyp, histF=allF, proposals=int(np.sum(ntries)))

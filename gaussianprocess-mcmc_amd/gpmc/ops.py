@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import KB_FULL, KB_LOWER, KB_PAD_IDENTITY, KERNEL_MATERN52_ARD, KERNEL_RBF, check, pad  # noqa: F401
+from ._lib import KB_FULL, KB_LOWER, KB_PAD_IDENTITY, KERNEL_MATERN52_ARD, KERNEL_RBF, PAD, check, pad  # noqa: F401
 
 KERNELS = {'rbf': KERNEL_RBF, 'matern52ard': KERNEL_MATERN52_ARD}
 

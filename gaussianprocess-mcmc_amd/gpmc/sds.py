@@ -1,0 +1,179 @@
+"""Device-resident auxiliary-variable model of surrogate-data slice sampling.
+
+Mirror of ``aux_var_model`` (kcMCMC/sliceSample.py:165-207) plus the two expressions that consume it
+(``ita``, sliceSample.py:108; ``prop_f``, :140; ``curG``/``propG``, :122,147), with every dense step a
+libgpmc kernel and nothing but scalars and N-vectors crossing to the host:
+
+    workspace A, (2 np_ + 128) x np_ :  rows [0, np_)       K + S   (lower; S_ii fused by the K build)
+                                        rows [np_, 2 np_)   K       (full; becomes V^T = K L^-T)
+                                        row  2 np_          g       (becomes alpha^T = (L^-1 g)^T)
+    gpmc_potrf(A)                    -> L, V^T, alpha in one factorisation            (a3, a4, a11's TRSV)
+    workspace R, (np_ + 128) x np_   :  K (lower) -> gpmc_syrk_diff -> R = K - V^T V   (a5)
+    m = gpmc_symv_lower(R, g / S)                                                       (a6)
+    R += 1e-11 I ; row np_ = f - m ; gpmc_potrf(R) -> C = chol(R), eta = C^-1 (f - m)   (a7, a9)
+    f' = gpmc_trmv_lower(C, eta) + m                                                    (a10)
+
+The reference spends ~11.3 N^3 flops here (dense S, LU solves, two inverses); this path 8 N^3 / 3.
+"""
+import numpy as np
+import torch
+
+from . import covK, ops
+
+R_JITTER = 1e-11          # sliceSample.py:205
+
+
+class SDSWorkspace(object):
+    def __init__(self, x, kernel='rbf', dtype=torch.float64):
+        ops.require_gpu()
+        self.kernel = kernel
+        self.dtype = dtype
+        self.X = ops.to_dev(x, dtype)
+        if self.X.dim() == 1:
+            self.X = self.X.reshape(-1, 1)
+        self.n, self.d = self.X.shape
+        dev = self.X.device
+        n = self.n
+        self.np_ = np_ = ops.pad(n)
+        self.mpA = 2 * np_ + ops.PAD
+        self.mpR = np_ + ops.PAD
+        self.WA = torch.zeros((self.mpA, np_), dtype=dtype, device=dev)
+        self.WR = torch.zeros((self.mpR, np_), dtype=dtype, device=dev)
+        self.infoA = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.infoR = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = ops.potrf_scratch(np_, dev)
+        self.out = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.kpS = torch.zeros(2 + (1 if kernel == 'rbf' else self.d), dtype=dtype, device=dev)
+        self.kp0 = torch.zeros_like(self.kpS)
+        self.m = torch.zeros(n, dtype=dtype, device=dev)
+        self.gs = torch.zeros(n, dtype=dtype, device=dev)
+        self.prop_f = torch.zeros(n, dtype=dtype, device=dev)
+
+    # ------------------------------------------------------------------ pieces
+    def _set_hyp(self, hyp):
+        kobj, sn = covK.kernel_from_hyp(hyp, self.kernel, self.dtype)
+        kp = kobj.kparams()
+        self.Sii = covK.s_diag_scalar(kp[0], sn)        # S = Sii * I : the kernel diagonal is the constant sf2
+        kp0 = kp.copy()
+        kp[1] = self.Sii
+        self.kpS.copy_(torch.as_tensor(kp, dtype=self.dtype))
+        self.kp0.copy_(torch.as_tensor(kp0, dtype=self.dtype))
+
+    def _factor_A(self, g, jitter):
+        """K + S (+ jitter) with K and g riding: L, V^T = K L^-T, alpha = L^-1 g, then the log-marginal reduction"""
+        n, np_ = self.n, self.np_
+        if jitter:
+            self.kpS[1] = self.Sii + jitter
+        ops.kbuild(self.kernel, self.X, self.kpS, self.WA, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+        ops.kbuild(self.kernel, self.X, self.kp0, self.WA[np_:2 * np_], np_, np_, ops.KB_FULL)
+        self.WA[2 * np_, :n].copy_(g)
+        ops.potrf(self.WA, self.mpA, np_, self.infoA, self.scratch)
+        ops.logdet_quad(self.WA, n, self.WA[2 * np_], self.infoA, self.out)
+
+    def _factor_R(self, f, g, need_eta, jitter):
+        """R = K - V^T V, m = R S^-1 g, C = chol(R + (1e-11 + jitter) I), eta = C^-1 (f - m)"""
+        n, np_ = self.n, self.np_
+        ops.kbuild(self.kernel, self.X, self.kp0, self.WR, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+        ops.syrk_diff(self.WR, self.WA[np_:2 * np_], np_, self.WR, n, np_, 0.0)
+        torch.div(g, self.Sii, out=self.gs)                      # O(N) vector scaling (S^-1 g)
+        ops.symv_lower(self.WR, n, self.gs, self.m)
+        if jitter:
+            self._Rdiag_mean = float(self.WR.diagonal()[:n].mean())
+        self.WR.diagonal()[:n].add_(R_JITTER + jitter)
+        if need_eta:
+            torch.sub(f, self.m, out=self.WR[np_, :n])
+        else:
+            self.WR[np_, :n].zero_()
+        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratch)
+
+    def aux_var_model(self, f, hyp, g, need_eta, maxtries=5):
+        """Factor everything for hyper-parameters ``hyp`` given latent f and auxiliary g (device vectors).
+
+        Returns G = log N(g; 0, K + S); afterwards self.m, the lower triangle of self.WR (= chol_R_theta),
+        self.eta (if need_eta) and self.WA (L, V^T, alpha) are valid.  A failed factorisation follows the
+        jitchol schedule the reference pins (pyGPs 1.3.4): mean(diag) * 1e-9 added, x10 per retry, ``maxtries``
+        retries, then np.linalg.LinAlgError propagates to the caller exactly as in the reference."""
+        self._set_hyp(hyp)
+        self._factor_A(g, 0.0)
+        self._factor_R(f, g, need_eta, 0.0)
+        res = self.out.cpu().numpy()                             # the one sync of the happy path (scalars)
+        infoA, infoR = int(res[3]), int(self.infoR.item())
+        if infoA != 0:
+            diag_mean = float(self.kp0[0]) + self.Sii            # diag(K + S) is constant and positive
+            jitter = diag_mean * 1e-9
+            for _ in range(maxtries):
+                self._factor_A(g, jitter)
+                self._factor_R(f, g, need_eta, 0.0)
+                res = self.out.cpu().numpy()
+                infoA, infoR = int(res[3]), int(self.infoR.item())
+                if infoA == 0:
+                    break
+                jitter *= 10.
+            else:
+                raise np.linalg.LinAlgError('not positive definite, even with jitter.')
+        if infoR != 0:
+            self._factor_R(f, g, need_eta, 1e-300)               # also measures mean(diag R)
+            if not self._Rdiag_mean > 0:
+                raise np.linalg.LinAlgError('not pd: non-positive diagonal elements')
+            jitter = self._Rdiag_mean * 1e-9
+            for _ in range(maxtries):
+                self._factor_R(f, g, need_eta, jitter)
+                if int(self.infoR.item()) == 0:
+                    break
+                jitter *= 10.
+            else:
+                raise np.linalg.LinAlgError('not positive definite, even with jitter.')
+        return float(res[0])
+
+    @property
+    def eta(self):
+        return self.WR[self.np_, :self.n]
+
+    def propose_f(self, eta):
+        """f' = C eta + m  (sliceSample.py:140)"""
+        return ops.trmv_lower(self.WR, self.n, eta, self.m, self.prop_f)
+
+    # ------------------------------------------------------------------ dense views (tests / drop-in protocol)
+    def L_KS(self):
+        return ops.unpack_lower(self.WA, self.np_, self.n)
+
+    def chol_R(self):
+        return ops.unpack_lower(self.WR, self.np_, self.n)
+
+
+def aux_var_model(f, K, sn, g=None, kernel_ws=None):
+    """Protocol-compatible ``aux_var_model(f, K, sn, g=None)`` -> (g, K+S, m_theta_g, chol_R_theta, L)
+    for a dense K handed in by the caller (ndarray or device tensor); everything returned is a device
+    tensor.  Slower than SDSWorkspace (K is packed instead of built in place) -- it exists so code written
+    against the reference's function keeps working."""
+    from . import tools
+    Kd = ops.to_dev(K)
+    n = Kd.shape[0]
+    f = ops.to_dev(f).reshape(-1)
+    Kii = torch.diagonal(Kd)
+    kinv = 1. / Kii
+    Sii = torch.clamp(1. / (((sn ** 2) ** (-1) + kinv) - kinv), min=0.)
+    if g is None:
+        g = f + torch.sqrt(Sii) * ops.to_dev(np.random.standard_normal(n))    # legacy stream, see oracle.draw_g
+    else:
+        g = ops.to_dev(g).reshape(-1)
+    np_ = ops.pad(n)
+    ws = tools.FactorWorkspace(n, n, Kd.dtype, Kd.device)
+    KS = Kd + torch.diag(Sii)
+    ops.pack_lower(KS, ws.W, np_, 0.0)
+    ops.pack_rows(Kd, ws.W, ws.mp, np_, n)
+    ws.factor()
+    if ws.info_host() != 0:
+        raise np.linalg.LinAlgError('K + S not positive definite (pivot %d)' % ws.info_host())
+    L = ops.unpack_lower(ws.W, np_, n)
+    wr = tools.FactorWorkspace(n, 0, Kd.dtype, Kd.device)
+    ops.pack_lower(Kd, wr.W, np_, 0.0)
+    ops.syrk_diff(wr.W, ws.W[np_:], ws.mp - np_, wr.W, n, np_, 0.0)
+    m = torch.empty(n, dtype=Kd.dtype, device=Kd.device)
+    ops.symv_lower(wr.W, n, g / Sii, m)
+    wr.W.diagonal()[:n].add_(R_JITTER)
+    wr.factor()
+    if wr.info_host() != 0:
+        raise np.linalg.LinAlgError('R not positive definite (pivot %d)' % wr.info_host())
+    C = ops.unpack_lower(wr.W, np_, n)
+    return g, KS, m, C, L

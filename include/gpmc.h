@@ -146,8 +146,11 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
                      size_t workspace_bytes, gpmc_stream_t stream);
 /* X: n x d host or device row-major (copied into the workspace), g: n elements */
 int gpmc_plan_set_data(gpmc_plan* p, const void* X_dev, int ldx, const void* g_dev);
-/* asynchronous: enqueue one evaluation; result lands in the plan's device result slot `slot` (0..63) */
-int gpmc_plan_logml_async(gpmc_plan* p, const double* hyp_host, int nhyp, int slot);
+/* asynchronous: enqueue one evaluation; the result lands in host result slot `slot` (0..63).
+ * kparams_host = kernel-ready parameters in gpmc_kbuild's hyp layout, as doubles: [sf^2, S_ii, ell...]
+ * (nk = 3 for RBF, 2 + d for ARD) -- the caller forms them from the sampler's (ell, sf, sn) exactly as the
+ * reference does: exp(log .) round trips and the S_ii expression of sliceSample.py:184-187. */
+int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int slot);
 /* synchronise the plan's stream and read result slot: out_host[0]=logml, [1]=logdet, [2]=quad, [3]=info */
 int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
 /* device pointer / geometry of the factored workspace of the last evaluation (for callers that go on
@@ -155,7 +158,14 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
 int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
 int gpmc_plan_destroy(gpmc_plan* p);
 
-/* tuning knobs (process-wide): outer block (multiple of 128), look-ahead on/off, graph on/off */
+/* instrumentation of the dominant kernel (the trailing SYRK update of gpmc_potrf): between begin and read every
+ * launch of it is bracketed by HIP events on its stream; read() returns out3 = {total ms inside the kernel,
+ * number of launches, algorithmic flops (2 K x lower-triangle elements updated)}.  Not for graph capture. */
+int gpmc_profile_begin(void);
+int gpmc_profile_read(double* out3);
+
+/* tuning knobs (process-wide): "outer_nb" (multiple of 128), "lookahead", "use_graph", "small_tile_m",
+ * "panel_impl", "diag_impl" */
 int gpmc_set_option(const char* name, int value);
 int gpmc_get_option(const char* name);
 

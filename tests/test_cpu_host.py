@@ -1,0 +1,115 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gpmc.h declares, host logic of the
+mirrors, and the N > 1 chain-gather path over gloo with world_size 2.  No GPU compute here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'gpmc.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(gpmc_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    import __graft_entry__ as ge
+    ge.build()
+    from gpmc import _lib
+    lib = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for nm in names:
+        assert hasattr(lib, nm), 'include/gpmc.h declares %s but libgpmc.so does not export it' % nm
+    assert lib.gpmc_version() == 100
+    assert lib.gpmc_pad(200) == 256 and lib.gpmc_pad(8192) == 8192
+    assert lib.gpmc_potrf_scratch_bytes(256) > 0
+    assert lib.gpmc_plan_workspace_bytes(8192, 2, 8) > 8192 * 8192 * 8
+    assert lib.gpmc_plan_workspace_bytes(0, 2, 8) == 0
+    # bad arguments are refused with a message, without touching a device
+    assert lib.gpmc_set_option(b'no_such_option', 1) != 0 and b'unknown option' in lib.gpmc_last_error()
+    assert lib.gpmc_set_option(b'outer_nb', 100) != 0
+    assert lib.gpmc_potrf_f64(None, 128, 128, 128, None, None, None) < 0
+
+
+def test_product_path_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from gpmc import _lib, core, covK, tools
+    with pytest.raises(_lib.GpmcError):
+        covK.RBF(0., 0.).getCovMatrix(x=np.zeros((4, 1)), mode='train')
+    with pytest.raises(_lib.GpmcError):
+        tools.jitchol(np.eye(3))
+    with pytest.raises(_lib.GpmcError):
+        core.LogMarginalPlan(np.zeros((4, 1)), np.zeros(4))
+
+
+def test_host_helpers_match_oracle():
+    from gpmc import covK, likK, sliceSample
+    from oracle import sds_ref
+    from oracle.kcgp_ref import likK as olik
+    hyp = np.array([0.35, 2.0, 0.2])
+    k, sn = covK.kernel_from_hyp(hyp)
+    kp = k.kparams()
+    assert kp[0] == np.exp(2. * np.log(2.0)) and kp[2] == np.exp(np.log(0.35)) and sn == 0.2
+    assert covK.s_diag_scalar(kp[0], sn) == sds_ref.s_diag(np.array([kp[0]]), sn)[0]
+    ka = covK.MaternARD52(np.log([1., 2., 3.]), np.log(1.5)).kparams(0.5)
+    np.testing.assert_allclose(ka, [2.25, 0.5, 1., 2., 3.])
+    rng = np.random.RandomState(0)
+    y, mu = rng.uniform(-40, 40, 50), rng.uniform(-40, 40, 50)
+    a = likK.TruncatedGauss2(upper=50., lower=-50., log_sigma=np.log(1.3))
+    b = olik.TruncatedGauss2(upper=50., lower=-50., log_sigma=np.log(1.3))
+    assert a.evaluate(y=y, mu=mu) == b.evaluate(y=y, mu=mu)
+    for u, v in zip(a.evaluate(mu=mu, s2=np.full(50, 0.4)), b.evaluate(mu=mu, s2=np.full(50, 0.4))):
+        np.testing.assert_array_equal(u, v)
+    x = np.array([1., 10., 1.2])
+    np.testing.assert_array_equal(sliceSample.log_gamma(x, sliceSample.PRIOR_K, sliceSample.PRIOR_THETA, True)[0],
+                                  sds_ref.log_gamma(x, sds_ref.PRIOR_K, sds_ref.PRIOR_THETA, True)[0])
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, 'gaussianprocess-mcmc_amd'))
+from gpmc import chains
+
+def fake_chain(x, y, iters, hyp0):
+    # stands in for the GPU sampler: consumes the rank's seeded legacy stream
+    h = np.random.uniform(size=(3, iters))
+    f = np.random.standard_normal((len(y), iters))
+    return f, h, np.ones(iters, dtype=np.int64)
+
+x = np.zeros((5, 1)); y = np.zeros(5)
+out = chains.run_chains(x, y, 4, (1., 10., 1.2), seed_base=124, gather_f=True, chain_fn=fake_chain)
+assert out['world'] == 2 and out['histHyp'].shape == (2, 3, 4) and out['histF'].shape == (2, 5, 4)
+for r in range(2):
+    np.random.seed(124 + r)
+    h = np.random.uniform(size=(3, 4)); f = np.random.standard_normal((5, 4))
+    assert np.array_equal(out['histHyp'][r], h) and np.array_equal(out['histF'][r], f)
+print('rank', out['rank'], 'ok')
+'''
+
+
+def test_chain_gather_world_size_2_gloo(tmp_path):
+    """N > 1 path: one chain per rank, seeds base + rank, one all_gather of the histories (gloo, CPU)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29531', str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('ok') == 2
+
+
+def test_single_process_gather_is_identity():
+    from gpmc import chains
+    h = np.arange(12.).reshape(3, 4)
+    a, b = chains.gather_histories(h, None)
+    assert a.shape == (1, 3, 4) and b is None and np.array_equal(a[0], h)
