@@ -1,0 +1,145 @@
+// gemm4.h -- FP64 NT GEMM / SYRK on v_mfma_f64_4x4x4_4b_f64.
+//
+// Measured on MI355X (scripts/mfma_peak.hip): v_mfma_f64_16x16x4_f64 saturates at ~49 TF/s, the 4-block
+// v_mfma_f64_4x4x4_4b_f64 at ~74 TF/s (the 78.6 TF/s FP64 spec rate).  One 4x4x4 instruction multiplies four
+// independent (4x4)(4x4) block pairs; feeding all four blocks the SAME A block (lane 16k+4blk+i reads A[i][k]
+// whatever blk is -- an LDS broadcast) and four adjacent B blocks turns it into a (4x4)(4x16) product whose
+// result, lane 16i + c -> C[i][c], is a 4-row x 16-column slab: the same register image as one register of the
+// 16x16x4 accumulator, with 128-byte row segments for the C read-modify-write.
+//   wave tile  = RG row-groups (4 rows) x CG column-groups (16 columns): RG*CG independent accumulators
+//   per 8 k    = RG + CG 16-byte LDS reads for 2*RG*CG MFMAs (16 cycles each)
+// Same interface and tile decode as gemm_nt_kernel (potrf.hip).
+#pragma once
+#include "gpmc_common.h"
+
+namespace gpmc {
+
+constexpr int G4_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
+
+template <int WGM, int WGN, int RG, int CG, bool EPI>
+__global__ void __launch_bounds__(256, 2)
+gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
+                int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
+                double diag_add) {
+    constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
+    constexpr int NA = BM * 8 / 256, NBI = BN * 8 / 256;   // 16-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem4[];
+    char* As = smem4;                       // [2][BM][G4_ROWB]
+    char* Bs = smem4 + 2 * BM * G4_ROWB;    // [2][BN][G4_ROWB]
+
+    int ti, tj;
+    {
+        const int b = blockIdx.x;
+        if (tri) {
+            const int T3 = ntc * (ntc + 1) / 2;
+            if (b < T3) {
+                ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+                while (ti * (ti + 1) / 2 > b) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+                tj = b - ti * (ti + 1) / 2;
+            } else {
+                const int bb = b - T3;
+                ti = ntc + bb / ntc;
+                tj = bb % ntc;
+            }
+        } else {
+            ti = b / ntc;
+            tj = b % ntc;
+        }
+    }
+    const int row0 = ti * BM, col0 = tj * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WGN, wn = wv % WGN;
+    const int i = lane >> 4, c = lane & 15, ia = lane & 3;   // i doubles as the operands' k index
+
+    double acc[RG][CG];
+    const int crow = row0 + wm * RG * 4 + i;        // + 4*rg
+    const int ccol = col0 + wn * CG * 16 + c;       // + 16*cg
+    if (beta) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) acc[rg][cg] = Cin[(size_t)(crow + 4 * rg) * ldcin + ccol + 16 * cg];
+    } else {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) acc[rg][cg] = 0.0;
+    }
+
+    const double* Ag = A + (size_t)row0 * lda;
+    const double* Bg = B + (size_t)col0 * ldb;
+    d2_t pa[NA], pb[NBI];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int ch = tid + 256 * t;
+            pa[t] = *reinterpret_cast<const d2_t*>(Ag + (size_t)(ch >> 3) * lda + k0 + (ch & 7) * 2);
+        }
+#pragma unroll
+        for (int t = 0; t < NBI; ++t) {
+            const int ch = tid + 256 * t;
+            pb[t] = *reinterpret_cast<const d2_t*>(Bg + (size_t)(ch >> 3) * ldb + k0 + (ch & 7) * 2);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int ch = tid + 256 * t;
+            d2_t v = pa[t];
+            v[0] *= alpha; v[1] *= alpha;
+            *reinterpret_cast<d2_t*>(As + ((size_t)buf * BM + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NBI; ++t) {
+            const int ch = tid + 256 * t;
+            *reinterpret_cast<d2_t*>(Bs + ((size_t)buf * BN + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = pb[t];
+        }
+    };
+
+    const int nk = K / 16;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * 16);
+        // A: lane (k = l>>4, blk, i = l&3) reads row 4rg+i ; B: lane (k = l>>4, col = l&15) reads row 16cg+col
+        const char* Ab = As + ((size_t)cur * BM + wm * RG * 4 + ia) * G4_ROWB + i * 16;
+        const char* Bb = Bs + ((size_t)cur * BN + wn * CG * 16 + c) * G4_ROWB + i * 16;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            d2_t bf[CG];
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) bf[cg] = *reinterpret_cast<const d2_t*>(Bb + cg * 16 * G4_ROWB + kc * 64);
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const d2_t af = *reinterpret_cast<const d2_t*>(Ab + rg * 4 * G4_ROWB + kc * 64);
+                // the two k-halves of one accumulator are issued CG instructions apart (no back-to-back dependence)
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg)
+                    acc[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[0], bf[cg][0], acc[rg][cg], 0, 0, 0);
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg)
+                    acc[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[1], bf[cg][1], acc[rg][cg], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int gr = crow + 4 * rg, gc = ccol + 16 * cg;
+            double v = acc[rg][cg];
+            if (EPI) {
+                if (gr == gc) v += diag_add;
+                if (gr >= n_true || gc >= n_true) v = (gr == gc) ? 1.0 : 0.0;
+            }
+            C[(size_t)gr * ldc + gc] = v;
+        }
+}
+
+}  // namespace gpmc

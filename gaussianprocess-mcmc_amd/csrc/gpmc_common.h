@@ -38,6 +38,7 @@ struct Options {
                           // both kernels want every CU's LDS/VGPRs; kept as an option)
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
+    int gemm_impl = 1;        // 1: v_mfma_f64_4x4x4 slab GEMM (f64), 0: v_mfma_*_16x16x4 GEMM
     int panel_impl = 1;       // 1: fused update+factor+TRSM kernel per 64 columns (f64), 0: three kernels
     int diag_impl = 3;        // 0: LDS column loop, 1: single wave, 2: register-blocked VALU, 3: micro-panel + MFMA 4x4x4
 };

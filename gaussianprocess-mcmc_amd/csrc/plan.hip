@@ -97,6 +97,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
     else if (!strcmp(name, "diag_impl")) g_opt.diag_impl = value;
     else if (!strcmp(name, "panel_impl")) g_opt.panel_impl = value;
+    else if (!strcmp(name, "gemm_impl")) g_opt.gemm_impl = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -108,6 +109,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "small_tile_m")) return g_opt.small_tile_m;
     if (!strcmp(name, "diag_impl")) return g_opt.diag_impl;
     if (!strcmp(name, "panel_impl")) return g_opt.panel_impl;
+    if (!strcmp(name, "gemm_impl")) return g_opt.gemm_impl;
     return -1;
 }
 

@@ -24,6 +24,7 @@
 #include "diag_rb.h"
 #include "diag_mp.h"
 #include "panel_fused.h"
+#include "gemm4.h"
 
 namespace gpmc {
 
@@ -319,6 +320,21 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
         nblk = mt * ntc;
     }
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
+    if constexpr (sizeof(T) == 8) {
+        if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
+            auto k4 = gemm4_nt_kernel<WGM, WGN, 4 * TM, TN, EPI>;
+            static bool attr4_done = false;
+            if (!attr4_done) {
+                GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr4_done = true;
+            }
+            hipLaunchKernelGGL(k4, dim3(nblk), dim3(256), smem, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
+                               alpha, beta, n_true, diag_add);
+            GPMC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     auto kern = gemm_nt_kernel<T, WGM, WGN, TM, TN, EPI>;
     static bool attr_done = false;  // per template instantiation
     if (!attr_done) {
