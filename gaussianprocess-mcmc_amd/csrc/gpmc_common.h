@@ -122,6 +122,8 @@ struct Aux {
     bool ready = false;
 };
 int aux_get(Aux** out);
+int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, hipStream_t s);
+int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s);
 int profile_begin();
 int profile_read(double* out);
 

@@ -179,6 +179,91 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     }
 }
 
+// Stand-alone TRSM of one 64-column block for rows that are NOT part of a factorisation in progress
+// (gpmc_trsm_rows): X = S L_d^-T with L_d given (only its lower triangle is read).  Phases 2.5-4 of
+// panel_block_kernel.
+struct TrsmShared {
+    double Lout[64][MP_LD];
+    double Ls[64][MP_LD];
+    double Linv[16][4][4];
+};
+
+__global__ void __launch_bounds__(256)
+trsm_block_kernel(const double* __restrict__ Ld, int ld, double* __restrict__ R, int ldr) {
+    extern __shared__ __attribute__((aligned(16))) char trsm_smem[];
+    TrsmShared& sh = *reinterpret_cast<TrsmShared*>(trsm_smem);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int i = lane >> 4, c = lane & 15, ia = lane & 3;
+    double* Rs = R + (size_t)64 * blockIdx.x * ldr;
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int row = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<d2_t*>(&sh.Lout[row][c2]) = *reinterpret_cast<const d2_t*>(&Ld[(size_t)row * ld + c2]);
+        *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = *reinterpret_cast<const d2_t*>(&Rs[(size_t)row * ldr + c2]);
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int o = 4 * tid;
+        const double l00 = sh.Lout[o][o], l10 = sh.Lout[o + 1][o], l11 = sh.Lout[o + 1][o + 1];
+        const double l20 = sh.Lout[o + 2][o], l21 = sh.Lout[o + 2][o + 1], l22 = sh.Lout[o + 2][o + 2];
+        const double l30 = sh.Lout[o + 3][o], l31 = sh.Lout[o + 3][o + 1], l32 = sh.Lout[o + 3][o + 2],
+                     l33 = sh.Lout[o + 3][o + 3];
+        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22, i33 = 1.0 / l33;
+        const double i10 = -(l10 * i00) * i11;
+        const double i21 = -(l21 * i11) * i22;
+        const double i32 = -(l32 * i22) * i33;
+        const double i20 = -(l20 * i00 + l21 * i10) * i22;
+        const double i31 = -(l31 * i11 + l32 * i21) * i33;
+        const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
+        double(*V)[4] = sh.Linv[tid];
+        V[0][0] = i00; V[0][1] = 0.0; V[0][2] = 0.0; V[0][3] = 0.0;
+        V[1][0] = i10; V[1][1] = i11; V[1][2] = 0.0; V[1][3] = 0.0;
+        V[2][0] = i20; V[2][1] = i21; V[2][2] = i22; V[2][3] = 0.0;
+        V[3][0] = i30; V[3][1] = i31; V[3][2] = i32; V[3][3] = i33;
+    }
+    double T[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) T[g] = sh.Ls[16 * w + c][4 * g + i];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const double av = sh.Linv[p][ia][i];
+        const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T[p], 0.0, 0, 0, 0);
+        T[p] = Y;
+#pragma unroll
+        for (int g = p + 1; g < 16; ++g) {
+            const double al = -sh.Lout[4 * g + ia][4 * p + i];
+            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = T[g];
+    __syncthreads();
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int row = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<d2_t*>(&Rs[(size_t)row * ldr + c2]) = *reinterpret_cast<const d2_t*>(&sh.Ls[row][c2]);
+    }
+}
+
+// Lt[i][j] = L[n-1-j][n-1-i] for j <= i, 0 above: the reverse-transpose J L^T J of a lower-triangular matrix is
+// lower triangular, and rows * L^-1 = ((rows J) Lt^-T) J turns the backward substitution into a forward one.
+__global__ void __launch_bounds__(256)
+revt_lower_kernel(const double* __restrict__ L, int n, int ld, double* __restrict__ Lt, int ldo) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int bi = blockIdx.y, bj = blockIdx.x;               // output tile (rows 32bi.., cols 32bj..)
+    if (bj > bi) return;
+    // source tile: rows n-1-(32bj+..), cols n-1-(32bi+..)
+    for (int r = ty; r < 32; r += 8) {
+        const int sr = n - 1 - (32 * bj + r), sc = n - 1 - (32 * bi + tx);
+        tile[r][tx] = (sc <= sr) ? L[(size_t)sr * ld + sc] : 0.0;     // tile[r][tx] = L[n-1-(32bj+r)][n-1-(32bi+tx)]
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int oi = 32 * bi + r, oj = 32 * bj + tx;
+        Lt[(size_t)oi * ldo + oj] = (oj <= oi) ? tile[tx][r] : 0.0;   // = L[n-1-oj][n-1-oi]
+    }
+}
+
 __global__ void __launch_bounds__(256)
 panel_flush_kernel(double* __restrict__ W, int ld, const double* __restrict__ lpark, int c0) {
     const double* src = lpark + (size_t)(c0 / 64) * 4096;

@@ -113,6 +113,12 @@ int gpmc_get_option(const char* name) {
     return -1;
 }
 
+int gpmc_trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, gpmc_stream_t stream) {
+    return trsm_rows_f64(W, np_, ldw, R, nrows, ldr, reinterpret_cast<hipStream_t>(stream));
+}
+int gpmc_revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, gpmc_stream_t stream) {
+    return revt_lower_f64(L, n, ld, Lt, ldo, reinterpret_cast<hipStream_t>(stream));
+}
 int gpmc_profile_begin(void) { return profile_begin(); }
 int gpmc_profile_read(double* out3) {
     if (!out3) return fail(-1, "gpmc_profile_read: null out");

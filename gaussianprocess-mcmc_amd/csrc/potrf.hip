@@ -556,6 +556,40 @@ int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C
     return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, D, ldd, C, ldc, np_, np_, kp, 1, (T)-1, 1, n, diag_add, s);
 }
 
+// rows (nrows x np_, ldr) <- rows L^-T with L the lower triangle of W (f64): 64-column blocks, MFMA TRSM on the
+// block then a rank-64 GEMM update of the columns to its right.
+int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, hipStream_t s) {
+    GPMC_ARG(W != nullptr && np_ > 0 && np_ % NB_IN == 0 && ldw >= np_, 1);
+    GPMC_ARG(R != nullptr && nrows > 0 && nrows % NB_IN == 0 && ldr >= np_ && ldr % 2 == 0, 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm_block_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsmShared)));
+        attr_done = true;
+    }
+    for (int c0 = 0; c0 < np_; c0 += NB_IN) {
+        hipLaunchKernelGGL(trsm_block_kernel, dim3(nrows / NB_IN), dim3(256), sizeof(TrsmShared), s,
+                           W + (size_t)c0 * ldw + c0, ldw, R + c0, ldr);
+        GPMC_LAUNCH_CHECK();
+        const int rest = np_ - c0 - NB_IN;
+        if (rest > 0) {
+            int rc = launch_gemm<double, 2, 2, 2, 2, false>(R + c0, ldr, W + (size_t)(c0 + NB_IN) * ldw + c0, ldw,
+                                                            R + c0 + NB_IN, ldr, R + c0 + NB_IN, ldr, nrows, rest,
+                                                            NB_IN, 0, -1.0, 1, 0, 0.0, s);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s) {
+    GPMC_ARG(L != nullptr && n > 0 && n % 32 == 0 && ld >= n, 1);
+    GPMC_ARG(Lt != nullptr && ldo >= n && Lt != L, 4);
+    hipLaunchKernelGGL(revt_lower_kernel, dim3(n / 32, n / 32), dim3(256), 0, s, L, n, ld, Lt, ldo);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
 template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t);
 template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t);
 template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);

@@ -115,6 +115,17 @@ def trmv_lower(W, n, x, y0, y):
     return y
 
 
+def trsm_rows(W, np_, R, nrows):
+    check(_lib.lib().gpmc_trsm_rows_f64(W.data_ptr(), np_, W.stride(0), R.data_ptr(), nrows, R.stride(0), stream_ptr()),
+          'gpmc_trsm_rows_f64')
+
+
+def revt_lower(L, n, out):
+    check(_lib.lib().gpmc_revt_lower_f64(L.data_ptr(), n, L.stride(0), out.data_ptr(), out.stride(0), stream_ptr()),
+          'gpmc_revt_lower_f64')
+    return out
+
+
 def potrf_scratch(np_, dev):
     nbytes = _lib.lib().gpmc_potrf_scratch_bytes(np_)
     return torch.empty(nbytes, dtype=torch.uint8, device=dev)

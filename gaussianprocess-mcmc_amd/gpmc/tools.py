@@ -63,3 +63,34 @@ def jitchol(A, maxtries=5, workspace=None):
             return ops.unpack_lower(ws.W, ws.np_, n)
         jitter *= 10.
     raise np.linalg.LinAlgError('not positive definite, even with jitter.')
+
+
+def solve_chol(L, B):
+    """X = (L^T L)^-1 B with ``L`` the UPPER factor (hence the ``.T`` at sliceSample.py:257) -- pyGPs'
+    ``solve(L, solve(L.T, B))``.  Two MFMA triangular row-solves on the device: the forward half on the lower
+    factor L^T, the backward half as a forward solve on its reverse-transpose (gpmc_revt_lower)."""
+    U = ops.to_dev(L, torch.float64)
+    if U.dim() != 2 or U.shape[0] != U.shape[1]:
+        raise ValueError('solve_chol needs a square factor')
+    n = U.shape[0]
+    Bd = ops.to_dev(B, torch.float64)
+    vec = Bd.dim() == 1
+    if vec:
+        Bd = Bd.reshape(-1, 1)
+    if Bd.shape[0] != n:
+        raise ValueError('B must have as many rows as the factor')
+    m = Bd.shape[1]
+    np_ = ops.pad(n)
+    mr = (m + 63) // 64 * 64
+    dev = U.device
+    Wl = torch.empty((np_, np_), dtype=torch.float64, device=dev)
+    ops.pack_lower(U.t().contiguous(), Wl, np_, 0.0)          # lower factor L^T with identity padding
+    R = torch.zeros((mr, np_), dtype=torch.float64, device=dev)
+    R[:m, :n] = Bd.t()
+    ops.trsm_rows(Wl, np_, R, mr)                              # rows <- rows (L^T)^-T : forward half
+    Wt = torch.empty((np_, np_), dtype=torch.float64, device=dev)
+    ops.revt_lower(Wl, np_, Wt)
+    Rj = R.flip(1).contiguous()                                # rows J  (data movement only)
+    ops.trsm_rows(Wt, np_, Rj, mr)
+    X = Rj.flip(1)[:m, :n].t().contiguous()
+    return X.reshape(-1) if vec else X

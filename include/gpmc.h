@@ -134,6 +134,16 @@ int gpmc_symv_lower_f32(const float* W, int n, int ldw, const float* x, float* y
 int gpmc_trmv_lower_f32(const float* W, int n, int ldw, const float* x, const float* y0, float* y,
                         gpmc_stream_t stream);
 
+/* ---- a16: triangular solves with an existing factor (tools.solve_chol, sliceSample.py:258; also :120,145,202) ----
+ * trsm_rows: R (nrows x np_, ldr; nrows multiple of 64) <- R L^-T, i.e. row r becomes (L^-1 b_r)^T, with L the lower
+ *            triangle of the workspace matrix W (np_ x np_).  f64.
+ * revt_lower: Lt = J L^T J (Lt[i][j] = L[n-1-j][n-1-i], lower triangular, strict upper zeroed).  Since
+ *            R L^-1 = ((R J) Lt^-T) J, the backward half of solve_chol is trsm_rows on Lt with the rows' columns
+ *            reversed.  n multiple of 32; Lt must not alias L.
+ */
+int gpmc_trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, gpmc_stream_t stream);
+int gpmc_revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, gpmc_stream_t stream);
+
 /* ---- fused plan: one log-marginal evaluation per call -------------------------------------------
  * The metric's unit (a1 + a2 + a3 + a11): for hyper-parameters hyp (host, linear
  * scale: ell[1 or d], sf, sn) build K + S into the plan's workspace, factor it with g riding as an

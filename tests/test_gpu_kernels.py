@@ -189,3 +189,18 @@ def test_log_marginal_f32_matern(gp):
     ref = sds_ref.gp_log_marginal(x, g, hyp, kernel='matern52ard')
     got = gp['core'].log_marginal(x, g, hyp, kernel='matern52ard', dtype=torch.float32)
     assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
+
+
+@pytest.mark.parametrize('n,m', [(7, 1), (64, 3), (200, 1), (455, 70), (1000, 130)])
+def test_solve_chol_matches_oracle(gp, n, m):
+    """tools.solve_chol(U, B) = (U^T U)^-1 B with U upper (sliceSample.py:257-258)"""
+    from oracle.kcgp_ref import tools as otools
+    A = _spd(n, 11)
+    U = scipy.linalg.cholesky(A, lower=False)
+    B = np.random.RandomState(12).standard_normal((n, m))
+    X = gp['tools'].solve_chol(U, B).cpu().numpy()
+    Xref = otools.solve_chol(U, B)
+    np.testing.assert_allclose(X, Xref, rtol=0, atol=1e-9 * np.abs(Xref).max())
+    np.testing.assert_allclose(A @ X, B, rtol=0, atol=1e-9 * np.abs(B).max() * np.linalg.cond(A) ** 0.5)
+    v = gp['tools'].solve_chol(U, B[:, 0]).cpu().numpy()
+    np.testing.assert_allclose(v, Xref[:, 0], rtol=0, atol=1e-9 * np.abs(Xref).max())
