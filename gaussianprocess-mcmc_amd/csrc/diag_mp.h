@@ -17,7 +17,7 @@
 
 namespace gpmc {
 
-constexpr int MP_LD = 66;   // Lout row stride (doubles)
+constexpr int MP_LD = 72;   // row stride (doubles): 576 B = 16 banks mod 64 -> the 4 rows x 4 k-pairs of a replicated A read hit 16 distinct bank groups
 constexpr int MP_PLD = 9;   // micro-panel row stride (doubles)
 
 __device__ inline double mp_readlane(double v, int lane) {
@@ -44,7 +44,7 @@ __device__ inline void mp_sqrt_rsqrt(double d, double& sq, double& rs) {
 // One micro-step, T8 compile-time.  All 256 threads call; two barriers inside.
 template <int T8>
 __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
-                                     int w, int lane, int gcol) {
+                                     double* rsd, int w, int lane, int gcol) {
     constexpr int HT = T8 >> 1;            // slab column that holds columns 8T8..8T8+7
     constexpr int CLO = 8 * (T8 & 1);      // first lane-column of the micro-panel inside that slab
     const int i = lane >> 4, c = lane & 15;
@@ -68,6 +68,7 @@ __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], d
             if (!(d > 0.0) && lane == 0 && *failp == 0) *failp = gcol + pr + 1;
             double sq, rs;
             mp_sqrt_rsqrt(d, sq, rs);
+            if (lane == 0) rsd[pr] = rs;                     // 1 / L[pr][pr], reused by the 4x4 inverses
             double lk = p[k] * rs;
             lk = (row == pr) ? sq : lk;
             lk = (row < pr) ? 0.0 : lk;
@@ -107,18 +108,18 @@ __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], d
 
 // Factor the block held in slabs; on return Lout holds L (strict upper zero).  gcol = global column of the block.
 __device__ inline void mp_factor64(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
-                                   int tid, int gcol) {
+                                   double* rsd, int tid, int gcol) {
     const int w = tid >> 6, lane = tid & 63;
     if (tid == 0) *failp = 0;
     __syncthreads();
-    mp_micro_step<0>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<1>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<2>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<3>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<4>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<5>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<6>(D, Lout, Praw, failp, w, lane, gcol);
-    mp_micro_step<7>(D, Lout, Praw, failp, w, lane, gcol);
+    mp_micro_step<0>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<1>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<2>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<3>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<4>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<5>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<6>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<7>(D, Lout, Praw, failp, rsd, w, lane, gcol);
     __syncthreads();
 }
 
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(256)
 diag_factor_mp_kernel(double* __restrict__ Wd, int ld, double* __restrict__ dinv, int* __restrict__ info, int c0) {
     __shared__ double Lout[64][MP_LD];
     __shared__ double Praw[64][MP_PLD];
+    __shared__ double rsd[64];
     __shared__ int sfail;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int i = lane >> 4, c = lane & 15;
@@ -136,7 +138,7 @@ diag_factor_mp_kernel(double* __restrict__ Wd, int ld, double* __restrict__ dinv
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             D[m][h] = (h <= m) ? Wd[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
-    mp_factor64(D, Lout, Praw, &sfail, tid, c0);
+    mp_factor64(D, Lout, Praw, &sfail, rsd, tid, c0);
     for (int e = tid; e < 64 * 64; e += 256) {
         const int r = e >> 6, cc = e & 63;
         Wd[(size_t)r * ld + cc] = Lout[r][cc];

@@ -20,7 +20,7 @@ template <int WGM, int WGN, int RG, int CG, bool EPI>
 __global__ void __launch_bounds__(256, 2)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
-                double diag_add) {
+                double diag_add, int g_desync, int xmap) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NA = BM * 8 / 256, NBI = BN * 8 / 256;   // 16-byte chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem4[];
@@ -28,7 +28,37 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     char* Bs = smem4 + 2 * BM * G4_ROWB;    // [2][BN][G4_ROWB]
 
     int ti, tj;
-    {
+    if (xmap) {
+        // XCD-aware order (workgroups b and b+8 share an XCD and its private 4 MB L2): every XCD walks 8x8
+        // super-blocks of tiles, so its ~64 resident workgroups touch 8 A-tiles + 8 B-tiles (2 MB, each reused
+        // 8x from L2) instead of ~72 distinct operand tiles.  mt = tile rows, ntc = tile columns; slots that fall
+        // outside the (lower-triangular) tile set exit at once.
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        const int sb = (slot >> 6) * 8 + xcd;              // super-block id
+        const int r = (slot & 63) >> 3, cc = slot & 7;     // tile inside the super-block
+        const int SC = (ntc + 7) >> 3;                     // super-columns
+        int I, J;
+        if (tri) {
+            const int T3 = SC * (SC + 1) / 2;
+            if (sb < T3) {
+                I = (int)((sqrt(8.0 * (double)sb + 1.0) - 1.0) * 0.5);
+                while (I * (I + 1) / 2 > sb) --I;
+                while ((I + 1) * (I + 2) / 2 <= sb) ++I;
+                J = sb - I * (I + 1) / 2;
+            } else {
+                const int bb = sb - T3;
+                I = SC + bb / SC;
+                J = bb % SC;
+            }
+        } else {
+            I = sb / SC;
+            J = sb % SC;
+        }
+        ti = 8 * I + r;
+        tj = 8 * J + cc;
+        if (ti >= xmap || tj >= ntc || (tri && tj > ti)) return;   // xmap carries mt (tile rows)
+    } else {
         const int b = blockIdx.x;
         if (tri) {
             const int T3 = ntc * (ntc + 1) / 2;
@@ -55,7 +85,19 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     double acc[RG][CG];
     const int crow = row0 + wm * RG * 4 + i;        // + 4*rg
     const int ccol = col0 + wn * CG * 16 + c;       // + 16*cg
-    if (beta) {
+    // Co-resident workgroups start in lock-step, so their C-tile reads (prologue) and writes (epilogue) would
+    // coincide and leave the MFMA pipe idle ~1/3 of a K=128 tile.  Every other dispatch wave of 256 workgroups
+    // therefore accumulates from zero and folds C in AFTER the K loop: one workgroup's memory phase then sits
+    // under its neighbour's MFMA phase.  (Which workgroups share a CU is a guess that only affects speed.)
+    const bool c_last = beta && (g_desync == 1) && ((blockIdx.x >> 8) & 1);
+    if (g_desync >= 2) {   // experiment: phase-shift part of the grid by ~g_desync/10 of a K=128 tile lifetime
+        const int sel = (g_desync & 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+        if (sel && blockIdx.x < 512) {
+            const int reps = g_desync >> 1;
+            for (int r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
+        }
+    }
+    if (beta && !c_last) {
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
@@ -134,6 +176,7 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
         for (int cg = 0; cg < CG; ++cg) {
             const int gr = crow + 4 * rg, gc = ccol + 16 * cg;
             double v = acc[rg][cg];
+            if (c_last) v += Cin[(size_t)gr * ldcin + gc];
             if (EPI) {
                 if (gr == gc) v += diag_add;
                 if (gr >= n_true || gc >= n_true) v = (gr == gc) ? 1.0 : 0.0;

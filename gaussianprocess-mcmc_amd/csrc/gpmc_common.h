@@ -33,11 +33,16 @@ inline int fail(int code, const char* fmt, ...) {
 
 // ---------------------------------------------------------------- options
 struct Options {
-    int outer_nb = 128;   // outer block of the right-looking Cholesky (multiple of 128)
-    int lookahead = 0;    // factor panel k+1 on a second stream while the trailing update of k runs (measured: no gain,
-                          // both kernels want every CU's LDS/VGPRs; kept as an option)
+    int outer_nb = 0;     // outer block of the right-looking Cholesky (multiple of 128); 0 = auto (128, or 256 with look-ahead)
+    int lookahead = -1;   // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: only for
+                          // np_ >= 6144, where the GEMM is long enough to hide the (contention-stretched) panel chain
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
+    int gemm_lds_pad = -1;    // -1 = auto (16000 under look-ahead, else 0)
+    int gemm_lds_pad_unused = 0;     // extra dynamic LDS bytes requested by the big-tile GEMM (>= 14000 -> 1 workgroup per CU,
+                              // leaving half of every CU to the look-ahead panel kernel)
+    int gemm_xcd_map = 0;     // 1: XCD-aware 8x8 super-block tile order in the 4x4x4 GEMM
+    int gemm_desync = 0;      // 1: alternate dispatch waves fold C in after the K loop (breaks the lock-step)
     int gemm_impl = 1;        // 1: v_mfma_f64_4x4x4 slab GEMM (f64), 0: v_mfma_*_16x16x4 GEMM
     int panel_impl = 1;       // 1: fused update+factor+TRSM kernel per 64 columns (f64), 0: three kernels
     int diag_impl = 3;        // 0: LDS column loop, 1: single wave, 2: register-blocked VALU, 3: micro-panel + MFMA 4x4x4
@@ -124,6 +129,8 @@ struct Aux {
 int aux_get(Aux** out);
 int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, hipStream_t s);
 int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s);
+int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
+                       unsigned long long* dbg_dev, hipStream_t s);
 int profile_begin();
 int profile_read(double* out);
 

@@ -27,12 +27,21 @@ struct PanelShared {
     double Ls[64][MP_LD];     // chunk of this strip's rows; later the strip block in / out
     double Praw[64][MP_PLD];
     double Linv[16][4][4];    // inverses of the 4x4 diagonal blocks of Lout
+    double rsd[64];           // 1 / L[j][j] from the micro-panel wave
     int fail;
 };
 
+// DBG = true is a diagnostic instantiation only (gpmc_debug_panel_stamps): wave 0 of workgroup 1 writes s_memtime
+// stamps at the phase boundaries into dbg[]; the production launch uses DBG = false and no stamp executes.
+#define PANEL_STAMP(k)                                                                         \
+    do {                                                                                       \
+        if (DBG && blockIdx.x == 1 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+
+template <bool DBG>
 __global__ void __launch_bounds__(256)
 panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
-                   double* __restrict__ lpark, int prev_c0) {
+                   double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char panel_smem[];
     PanelShared& sh = *reinterpret_cast<PanelShared*>(panel_smem);
     double (*Lout)[MP_LD] = sh.Ld;   // aliased: valid once phase 1 is over
@@ -40,6 +49,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;   // i doubles as the operands' k index (lane >> 4)
     const bool is_diag = (blockIdx.x == 0);
     const size_t R0 = (size_t)c0 + 64 * (size_t)blockIdx.x;
+    PANEL_STAMP(0);
 
     if (is_diag && prev_c0 >= 0) {   // flush the previous block's factor (nobody reads that block in this launch)
         const double* src = lpark + (size_t)(prev_c0 / 64) * 4096;
@@ -58,18 +68,37 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
 #pragma unroll
     for (int g = 0; g < 16; ++g) PT[g] = 0.0;
 
-    // ---------------- 1. left-looking products over the K = c0 - k0 finished columns of this outer panel
+    // ---------------- 0. issue the loads nothing depends on yet: the diagonal block's slabs and this strip's block
+    double Din[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            Din[m][h] = (h <= m) ? W[((size_t)c0 + 4 * (w + 4 * m) + i) * ld + c0 + 16 * h + c] : 0.0;
+
+    PANEL_STAMP(1);
+    // ---------------- 1. left-looking products over the K = c0 - k0 finished columns of this outer panel;
+    // the next 64-column chunk is fetched into registers while the current one is multiplied
+    d2_t pd[8], ps[8];
+    auto fetch_chunk = [&](int kc) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int e = tid + 256 * t, row = e >> 5, c2 = (e & 31) * 2;
+            pd[t] = *reinterpret_cast<const d2_t*>(&W[((size_t)c0 + row) * ld + kc + c2]);
+            if (!is_diag) ps[t] = *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + kc + c2]);
+        }
+    };
+    if (k0 < c0) fetch_chunk(k0);
     for (int kc = k0; kc < c0; kc += 64) {
         __syncthreads();
-        for (int e = tid; e < 64 * 32; e += 256) {
-            const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&sh.Ld[row][c2]) =
-                *reinterpret_cast<const d2_t*>(&W[((size_t)c0 + row) * ld + kc + c2]);
-            if (!is_diag)
-                *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) =
-                    *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + kc + c2]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int e = tid + 256 * t, row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&sh.Ld[row][c2]) = pd[t];
+            if (!is_diag) *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = ps[t];
         }
         __syncthreads();
+        if (kc + 64 < c0) fetch_chunk(kc + 64);
 #pragma unroll 2
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;   // this lane's k pair
@@ -79,31 +108,38 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
 #pragma unroll
             for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (w + 4 * m) + ia][ko]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
-                for (int h = 0; h <= m; ++h) {
-                    PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][0], bD[h][0], PD[m][h], 0, 0, 0);
-                    PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][1], bD[h][1], PD[m][h], 0, 0, 0);
-                }
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int h = 0; h <= m; ++h)
+                        PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][e2], bD[h][e2], PD[m][h], 0, 0, 0);
             if (!is_diag) {
                 const d2_t bT = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);
+                // two batches of 8 row-groups: 32 operand registers live instead of 64 (at 256 VGPRs the compiler
+                // parks accumulators in AGPRs and shuffles them around every MFMA)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const d2_t aT = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * g + ia][ko]);
-                    PT[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[0], bT[0], PT[g], 0, 0, 0);
-                    PT[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[1], bT[1], PT[g], 0, 0, 0);
+                for (int gb = 0; gb < 16; gb += 8) {
+                    d2_t aT[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) aT[g] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (gb + g) + ia][ko]);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g)
+                            PT[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[g][e2], bT[e2], PT[gb + g], 0, 0, 0);
                 }
             }
         }
     }
 
-    // ---------------- D = A_dd - P_D (slab layout straight from global: 4 rows x 128 B per load)
+    PANEL_STAMP(2);
+    // ---------------- D = A_dd - P_D
     double D[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-            D[m][h] = (h <= m) ? W[((size_t)c0 + 4 * (w + 4 * m) + i) * ld + c0 + 16 * h + c] - PD[m][h] : 0.0;
+        for (int h = 0; h < 4; ++h) D[m][h] = Din[m][h] - PD[m][h];
 
     // ---------------- T = (A_sd - P)^T : the strip block goes through LDS to be read transposed
     double T[16];
@@ -111,18 +147,19 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         __syncthreads();
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) =
-                *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + c0 + c2]);
+            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + c0 + c2]);
         }
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 16; ++g) T[g] = sh.Ls[16 * w + c][4 * g + i] - PT[g];
     }
 
+    PANEL_STAMP(3);
     // ---------------- 2. factor the diagonal block (every workgroup); Ld is dead from here on
     __syncthreads();
-    mp_factor64(D, Lout, sh.Praw, &sh.fail, tid, c0);
+    mp_factor64(D, Lout, sh.Praw, &sh.fail, sh.rsd, tid, c0);
 
+    PANEL_STAMP(4);
     if (is_diag) {
         double* dst = lpark + (size_t)(c0 / 64) * 4096;
         for (int e = tid; e < 64 * 32; e += 256) {
@@ -140,7 +177,8 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         const double l20 = Lout[o + 2][o], l21 = Lout[o + 2][o + 1], l22 = Lout[o + 2][o + 2];
         const double l30 = Lout[o + 3][o], l31 = Lout[o + 3][o + 1], l32 = Lout[o + 3][o + 2],
                      l33 = Lout[o + 3][o + 3];
-        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22, i33 = 1.0 / l33;
+        (void)l00; (void)l11; (void)l22; (void)l33;
+        const double i00 = sh.rsd[o], i11 = sh.rsd[o + 1], i22 = sh.rsd[o + 2], i33 = sh.rsd[o + 3];   // no divisions
         const double i10 = -(l10 * i00) * i11;
         const double i21 = -(l21 * i11) * i22;
         const double i32 = -(l32 * i22) * i33;
@@ -155,6 +193,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     }
     __syncthreads();
 
+    PANEL_STAMP(5);
     // ---------------- 3. TRSM: wave w solves its 16 strip rows (lanes c), 4-row slabs p = 0..15
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
@@ -168,6 +207,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         }
     }
 
+    PANEL_STAMP(6);
     // ---------------- 4. write the strip back (transpose through LDS, then 512-B row segments)
     __syncthreads();
 #pragma unroll
@@ -177,6 +217,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         const int row = e >> 5, c2 = (e & 31) * 2;
         *reinterpret_cast<d2_t*>(&W[(R0 + row) * ld + c0 + c2]) = *reinterpret_cast<const d2_t*>(&sh.Ls[row][c2]);
     }
+    PANEL_STAMP(7);
 }
 
 // Stand-alone TRSM of one 64-column block for rows that are NOT part of a factorisation in progress

@@ -91,13 +91,16 @@ size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * (1
 
 int gpmc_set_option(const char* name, int value) {
     if (!name) return fail(-1, "gpmc_set_option: null name");
-    if (!strcmp(name, "outer_nb")) { if (value < 128 || value % 128) return fail(-2, "outer_nb must be a multiple of 128"); g_opt.outer_nb = value; }
-    else if (!strcmp(name, "lookahead")) g_opt.lookahead = value ? 1 : 0;
+    if (!strcmp(name, "outer_nb")) { if (value != 0 && (value < 128 || value % 128)) return fail(-2, "outer_nb must be 0 (auto) or a multiple of 128"); g_opt.outer_nb = value; }
+    else if (!strcmp(name, "lookahead")) g_opt.lookahead = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(name, "use_graph")) g_opt.use_graph = value ? 1 : 0;
     else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
     else if (!strcmp(name, "diag_impl")) g_opt.diag_impl = value;
     else if (!strcmp(name, "panel_impl")) g_opt.panel_impl = value;
     else if (!strcmp(name, "gemm_impl")) g_opt.gemm_impl = value;
+    else if (!strcmp(name, "gemm_desync")) g_opt.gemm_desync = value;
+    else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
+    else if (!strcmp(name, "gemm_lds_pad")) g_opt.gemm_lds_pad = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -110,6 +113,9 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "diag_impl")) return g_opt.diag_impl;
     if (!strcmp(name, "panel_impl")) return g_opt.panel_impl;
     if (!strcmp(name, "gemm_impl")) return g_opt.gemm_impl;
+    if (!strcmp(name, "gemm_desync")) return g_opt.gemm_desync;
+    if (!strcmp(name, "gemm_xcd_map")) return g_opt.gemm_xcd_map;
+    if (!strcmp(name, "gemm_lds_pad")) return g_opt.gemm_lds_pad;
     return -1;
 }
 
@@ -118,6 +124,12 @@ int gpmc_trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, 
 }
 int gpmc_revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, gpmc_stream_t stream) {
     return revt_lower_f64(L, n, ld, Lt, ldo, reinterpret_cast<hipStream_t>(stream));
+}
+/* diagnostic only (not in gpmc.h): phase stamps of the fused panel kernel */
+int gpmc_debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, void* scratch, int np_,
+                            unsigned long long* dbg_dev, gpmc_stream_t stream) {
+    double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
+    return debug_panel_stamps(W, ld, mp, k0, c0, info_dev, lpark, dbg_dev, reinterpret_cast<hipStream_t>(stream));
 }
 int gpmc_profile_begin(void) { return profile_begin(); }
 int gpmc_profile_read(double* out3) {

@@ -32,6 +32,7 @@ Options g_opt;
 thread_local char g_err[512] = {0};
 
 static Aux g_aux;
+static int g_lds_pad_now = 0;   // extra dynamic LDS for the big-tile GEMM, decided per factorisation
 int aux_get(Aux** out) {
     if (!g_aux.ready) {
         int lo = 0, hi = 0;
@@ -326,11 +327,19 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
             static bool attr4_done = false;
             if (!attr4_done) {
                 GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr4_done = true;
             }
-            hipLaunchKernelGGL(k4, dim3(nblk), dim3(256), smem, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                               alpha, beta, n_true, diag_add);
+            const size_t smem4 = smem + ((BM == 128) ? (size_t)g_lds_pad_now : 0);
+            int xmap = 0, nblk4 = nblk;
+            if (g_opt.gemm_xcd_map && mt >= 16) {   // super-block order; grid = (#super-blocks rounded to 8) * 64
+                const int SC = (ntc + 7) / 8, SR = (mt + 7) / 8;
+                const int nsb = tri ? SC * (SC + 1) / 2 + (SR - SC) * SC : SR * SC;
+                nblk4 = ((nsb + 7) / 8 * 8) * 64;
+                xmap = mt;
+            }
+            hipLaunchKernelGGL(k4, dim3(nblk4), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
+                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap);
             GPMC_LAUNCH_CHECK();
             return 0;
         }
@@ -424,13 +433,14 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
     if (sizeof(T) == 8 && g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns
         static bool attr_done = false;
         if (!attr_done) {
-            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel),
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
             attr_done = true;
         }
         for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
-            hipLaunchKernelGGL(panel_block_kernel, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
-                               reinterpret_cast<double*>(W), ld, k0, c0, info_dev, lpark, c0 - NB_IN);
+            hipLaunchKernelGGL(panel_block_kernel<false>, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
+                               reinterpret_cast<double*>(W), ld, k0, c0, info_dev, lpark, c0 - NB_IN,
+                               (unsigned long long*)nullptr);
             GPMC_LAUNCH_CHECK();
         }
         return 0;
@@ -484,11 +494,16 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         GPMC_LAUNCH_CHECK();
         return 0;
     };
+    // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k, the
+    // GEMM held to one workgroup per CU so a panel workgroup always finds a slot) with NB = 256 for np_ >= 6144
+    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
+    if (NB <= 0) NB = la ? 256 : 128;
     if (NB < 128 || NB % 128) NB = 256;
+    g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? 16000 : 0) : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
-    if (!g_opt.lookahead || np_ <= NB) {
+    if (!la || np_ <= NB) {
         for (int k0 = 0; k0 < np_; k0 += NB) {
             const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
             int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
@@ -579,6 +594,17 @@ int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int l
             if (rc) return rc;
         }
     }
+    return 0;
+}
+
+// diagnostic: run the DBG instantiation of the panel kernel once on (W, k0, c0) and return 8 s_memtime stamps
+int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
+                       unsigned long long* dbg_dev, hipStream_t s) {
+    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
+    hipLaunchKernelGGL(panel_block_kernel<true>, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W, ld, k0,
+                       c0, info_dev, lpark, -1, dbg_dev);
+    GPMC_LAUNCH_CHECK();
     return 0;
 }
 

@@ -50,6 +50,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--la']:
+        for la, pad, nb in ((-1, -1, 0), (0, 0, 128), (1, 16000, 256), (-1, -1, 0)):
+            gpmc.set_option('lookahead', la), gpmc.set_option('gemm_lds_pad', pad), gpmc.set_option('outer_nb', nb)
+            print('lookahead', la, 'gemm_lds_pad', pad, 'outer_nb', nb)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--gemm']:
         for gi, stm, nb in ((0, 3072, 128), (1, 3072, 128), (0, 3072, 256), (1, 3072, 256), (1, 3072, 384)):
             gpmc.set_option('gemm_impl', gi), gpmc.set_option('small_tile_m', stm), gpmc.set_option('outer_nb', nb)

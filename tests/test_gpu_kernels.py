@@ -161,7 +161,7 @@ def test_log_marginal_options_agree(gp):
             vals.append([plan(hyp) for _ in range(3)])
             plan.close()
     finally:
-        gpmc.set_option('lookahead', 0), gpmc.set_option('use_graph', 1), gpmc.set_option('outer_nb', 128)
+        gpmc.set_option('lookahead', -1), gpmc.set_option('use_graph', 1), gpmc.set_option('outer_nb', 0)
     ref = sds_ref.gp_log_marginal(x, g, hyp)
     for v in vals:
         assert v[0] == v[1] == v[2]
