@@ -101,6 +101,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_desync")) g_opt.gemm_desync = value;
     else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
     else if (!strcmp(name, "gemm_lds_pad")) g_opt.gemm_lds_pad = value;
+    else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -116,6 +117,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_desync")) return g_opt.gemm_desync;
     if (!strcmp(name, "gemm_xcd_map")) return g_opt.gemm_xcd_map;
     if (!strcmp(name, "gemm_lds_pad")) return g_opt.gemm_lds_pad;
+    if (!strcmp(name, "la_min_m")) return g_opt.la_min_m;
     return -1;
 }
 

@@ -503,9 +503,10 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? 16000 : 0) : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
-    if (!la || np_ <= NB) {
-        for (int k0 = 0; k0 < np_; k0 += NB) {
-            const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
+    // serial schedule from column kstart on (the panel at kstart is factored first), outer block nbs
+    auto serial_from = [&](int kstart, int nbs) -> int {
+        for (int k0 = kstart; k0 < np_; k0 += nbs) {
+            const int nbk = (np_ - k0 < nbs) ? np_ - k0 : nbs;
             int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
             if (rc) return rc;
             const int k1 = k0 + nbk;
@@ -514,6 +515,12 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
             }
         }
+        return 0;
+    };
+    if (!la || np_ <= NB) {
+        g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
+        int rc = serial_from(0, NB);
+        if (rc) return rc;
         return final_flush();
     }
 
@@ -537,6 +544,15 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
         const int k1 = k0 + nbk;
         if (k1 >= np_) break;
+        if (np_ - k1 < g_opt.la_min_m) {
+            // tail: the GEMM no longer hides the (contention-stretched) panel chain -> serial, NB = 128, 2 WGs/CU
+            g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
+            int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+            if (rc) return rc;
+            rc = serial_from(k1, 128);
+            if (rc) return rc;
+            return final_flush();
+        }
         const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;  // next panel width
         // (1) next panel's columns, on s
         int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn, true);

@@ -57,6 +57,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--tail']:
+        for lm in (0, 3072, 4096, 5120, 6144, 7168):
+            gpmc.set_option('la_min_m', lm)
+            print('la_min_m', lm)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--gemm']:
         for gi, stm, nb in ((0, 3072, 128), (1, 3072, 128), (0, 3072, 256), (1, 3072, 256), (1, 3072, 384)):
             gpmc.set_option('gemm_impl', gi), gpmc.set_option('small_tile_m', stm), gpmc.set_option('outer_nb', nb)
