@@ -132,6 +132,8 @@ int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int l
 int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s);
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
                        unsigned long long* dbg_dev, hipStream_t s);
+int gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int M, int N, int K,
+                hipStream_t s);
 int profile_begin();
 int profile_read(double* out);
 

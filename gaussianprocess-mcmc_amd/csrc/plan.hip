@@ -127,6 +127,10 @@ int gpmc_trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, 
 int gpmc_revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, gpmc_stream_t stream) {
     return revt_lower_f64(L, n, ld, Lt, ldo, reinterpret_cast<hipStream_t>(stream));
 }
+int gpmc_gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int M, int N, int K,
+                     gpmc_stream_t stream) {
+    return gemm_nt_f64(A, lda, B, ldb, C, ldc, M, N, K, reinterpret_cast<hipStream_t>(stream));
+}
 /* diagnostic only (not in gpmc.h): phase stamps of the fused panel kernel */
 int gpmc_debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, void* scratch, int np_,
                             unsigned long long* dbg_dev, gpmc_stream_t stream) {

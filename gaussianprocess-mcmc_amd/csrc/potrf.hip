@@ -613,6 +613,15 @@ int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int l
     return 0;
 }
 
+// C (M x N, ldc) = A (M x K, lda) * B (N x K, ldb)^T, f64, M and N multiples of 64, K multiple of 16
+int gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int M, int N, int K,
+                hipStream_t s) {
+    GPMC_ARG(A && B && C, 1);
+    GPMC_ARG(M > 0 && N > 0 && K > 0 && M % 64 == 0 && N % 64 == 0 && K % 16 == 0, 7);
+    GPMC_ARG(lda >= K && ldb >= K && ldc >= N && lda % 2 == 0 && ldb % 2 == 0, 2);
+    return launch_gemm<double, 2, 2, 2, 2, false>(A, lda, B, ldb, C, ldc, C, ldc, M, N, K, 0, 1.0, 0, 0, 0.0, s);
+}
+
 // diagnostic: run the DBG instantiation of the panel kernel once on (W, k0, c0) and return 8 s_memtime stamps
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
                        unsigned long long* dbg_dev, hipStream_t s) {

@@ -6,11 +6,11 @@ is missing (there is no CPU fallback; the CPU oracle lives under ``oracle/`` and
 from . import _lib  # noqa: F401
 from ._lib import GpmcError, build, get_option, set_option  # noqa: F401
 
-__all__ = ['covK', 'likK', 'tools', 'core', 'ops', 'sliceSample', 'framework', 'chains', 'build', 'GpmcError']
+__all__ = ['covK', 'likK', 'tools', 'gpK', 'core', 'ops', 'sliceSample', 'framework', 'chains', 'build', 'GpmcError']
 
 
 def __getattr__(name):
-    if name in ('covK', 'likK', 'tools', 'core', 'ops', 'sliceSample', 'framework', 'chains'):
+    if name in ('covK', 'likK', 'tools', 'gpK', 'core', 'ops', 'sds', 'sliceSample', 'framework', 'chains'):
         import importlib
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

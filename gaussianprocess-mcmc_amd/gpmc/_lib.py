@@ -63,6 +63,7 @@ def _sig(lib):
         'gpmc_plan_destroy': ([P], I),
         'gpmc_trsm_rows_f64': ([P, I, I, P, I, I, P], I),
         'gpmc_revt_lower_f64': ([P, I, I, P, I, P], I),
+        'gpmc_gemm_nt_f64': ([P, I, P, I, P, I, I, I, I, P], I),
         'gpmc_profile_begin': ([], I),
         'gpmc_profile_read': ([ctypes.POINTER(c_double)], I),
         'gpmc_set_option': ([c_char_p, I], I),

@@ -61,3 +61,43 @@ def synthetic_demo_data(n=455, seed=124, ll=5.0, sf=20.0, sn=2.5, mean=91.153846
     z = ops.to_dev(np.random.normal(size=(n,)))
     y = torch.mv(L, z).cpu().numpy() + mean      # one O(N^2) product to draw the data, not on the hot path
     return x, y
+
+
+def output(x, y, gap=0, histHyp=None, histF=None, llk=None, outdir='./output'):
+    """CSV files in the reference's layout (Framework.output, framework.py:79-122): ``hypGap<gap>.csv`` with header
+    ll,sf2,sn and one row per hyper-parameter, ``fGap<gap>.csv`` with columns 1..iters,x,y, ``llkGap<gap>.csv``."""
+    import csv
+    import os
+    os.makedirs(outdir, exist_ok=True)
+    if histHyp is not None:
+        with open(os.path.join(outdir, 'hypGap%s.csv' % gap), 'w', newline='') as h:
+            w = csv.writer(h)
+            w.writerow(['ll', 'sf2', 'sn'])
+            w.writerows(histHyp)
+    if histF is not None:
+        with open(os.path.join(outdir, 'fGap%s.csv' % gap), 'w', newline='') as fh:
+            w = csv.writer(fh)
+            w.writerow(list(range(1, histF.shape[1] + 1)) + ['x', 'y'])
+            xy = np.hstack((np.asarray(x).reshape(-1, 1), np.asarray(y).reshape(-1, 1)))
+            w.writerows(np.hstack((histF, xy)))
+    if llk is not None:
+        with open(os.path.join(outdir, 'llkGap%s.csv' % gap), 'w', newline='') as k:
+            w = csv.writer(k)
+            w.writerow(['gap'] + [str(i) for i in range(len(llk))])
+            w.writerow([gap] + list(llk))
+    return 0
+
+
+def outputDemoRes(x, y, histF, histHyp, outdir='./output'):
+    """demoRegression.py:51-73: demo_f.csv (columns 1..n,x,y) and demo_hyp.csv (header ll,sf2,sn, one row per sample)."""
+    import csv
+    import os
+    os.makedirs(outdir, exist_ok=True)
+    with open(os.path.join(outdir, 'demo_f.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(list(range(1, histF.shape[1] + 1)) + ['x', 'y'])
+        w.writerows(np.hstack((histF, np.hstack((np.asarray(x).reshape(-1, 1), np.asarray(y).reshape(-1, 1))))))
+    with open(os.path.join(outdir, 'demo_hyp.csv'), 'w', newline='') as h:
+        w = csv.writer(h)
+        w.writerow(['ll', 'sf2', 'sn'])
+        w.writerows(histHyp.T)

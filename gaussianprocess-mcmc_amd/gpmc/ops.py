@@ -126,6 +126,13 @@ def revt_lower(L, n, out):
     return out
 
 
+def gemm_nt(A, B, C, M, N, K):
+    """C[:M,:N] = A[:M,:K] @ B[:N,:K].T (padded sizes: M, N multiples of 64, K of 16)"""
+    check(_lib.lib().gpmc_gemm_nt_f64(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0),
+                                      M, N, K, stream_ptr()), 'gpmc_gemm_nt_f64')
+    return C
+
+
 def potrf_scratch(np_, dev):
     nbytes = _lib.lib().gpmc_potrf_scratch_bytes(np_)
     return torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -101,3 +101,99 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
                 hyp_min[i] = prop_hyp[i]
             else:
                 hyp_max[i] = prop_hyp[i]
+
+
+def elliptical_slice(f, x, y, hyp, nu=None):
+    """Elliptical slice update of f for fixed hyper-parameters (sliceSample.py:15-74).
+
+    The prior draw nu ~ N(0, K) is ``chol(K) z`` on the device (gpmc_kbuild + gpmc_potrf + gpmc_trmv_lower) with z
+    from the legacy ``np.random`` stream; the reference uses ``multivariate_normal`` (an SVD of K), which consumes
+    the same number of normals but maps them differently, so chains are equal in distribution, not draw for draw.
+    The angle bracket loop is the reference's, draw for draw."""
+    from . import covK, tools
+    f = np.asarray(f, dtype=np.float64).reshape(-1)
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    nobs = f.shape[0]
+    my = np.mean(y)
+    if nu is None:
+        K = covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+        L = tools.jitchol(K)                                   # jitter schedule covers the numerically singular K
+        z = ops.to_dev(np.random.standard_normal(nobs))
+        nu_d = torch.empty(nobs, dtype=torch.float64, device=L.device)
+        ops.trmv_lower(L, nobs, z, None, nu_d)
+        nu = nu_d.cpu().numpy()
+    lik_func = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
+    cur_llk = lik_func.evaluate(y=y - my, mu=f) + np.log(np.random.uniform())
+    theta = np.random.uniform(high=2. * np.pi)
+    theta_min, theta_max = theta - 2. * np.pi, theta
+    while True:
+        prop_f = f * np.cos(theta) + nu * np.sin(theta)
+        prop_llk = lik_func.evaluate(y=y - my, mu=prop_f)
+        if prop_llk > cur_llk and np.isfinite(prop_llk):
+            return prop_f
+        if theta >= 0:
+            theta_max = theta
+        else:
+            theta_min = theta
+        theta = np.random.uniform(low=theta_min, high=theta_max)
+
+
+def inf_mcmc(f, model, ys=0):
+    """Predictive fs|f at ``model.xs`` from MCMC samples f (n, n_samples) -- sliceSample.py:234-284.
+
+    One device factorisation of K/sn^2 + I with BOTH solves riding on it: rows (f - m)^T give L^-1 (f - m) and rows
+    Ks^T / sn give V^T (sliceSample.py:257-258,269); the backward half of solve_chol is a forward row-solve on the
+    reverse-transposed factor; the predictive mean is one MFMA GEMM (gpmc_gemm_nt).  Returns numpy arrays
+    (ym, ys_lw, ys_up, Fs2) like the reference."""
+    x = np.asarray(model.x, dtype=np.float64)
+    x = x.reshape(-1, 1) if x.ndim == 1 else x
+    xs = np.asarray(model.xs, dtype=np.float64)
+    xs = xs.reshape(-1, 1) if xs.ndim == 1 else xs
+    y = np.asarray(model.y, dtype=np.float64)
+    f = np.asarray(f, dtype=np.float64)
+    my = np.mean(y)
+    n_samples = f.shape[1]
+    ns, n = xs.shape[0], x.shape[0]
+    m = np.tile(model.meanfunc.getMean(x), (1, n_samples))
+    sn2 = model.likfunc.sn ** 2.
+    cov = model.covfunc
+    dev = ops.device()
+    np_ = ops.pad(n)
+    r1 = (n_samples + 63) // 64 * 64                     # rows of (f - m)^T, padded
+    r2 = (ns + 63) // 64 * 64                            # rows of Ks^T / sn, padded
+    mp = np_ + ops.pad(r1 + r2)
+    W = torch.zeros((mp, np_), dtype=torch.float64, device=dev)
+    Xd, Xs = ops.to_dev(x), ops.to_dev(xs)
+    kp = cov.kparams()
+    kpA = kp.copy(); kpA[0] = kp[0] / sn2; kpA[1] = 1.0      # K / sn2 + I built in place
+    ops.kbuild(cov.kind, Xd, ops.to_dev(kpA), W, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+    W[np_:np_ + n_samples, :n] = ops.to_dev(f - m).t()
+    kpC = kp.copy(); kpC[1] = 0.0
+    KsT = torch.zeros((r2, np_), dtype=torch.float64, device=dev)
+    ops.kbuild(cov.kind, Xs, ops.to_dev(kpC), KsT, ns, n, ops.KB_FULL, Z=Xd)    # k(xs, x) = Ks^T, (ns, n)
+    W[np_ + r1:np_ + r1 + ns, :n] = KsT[:ns, :n] / np.sqrt(sn2)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.potrf(W, mp, np_, info, ops.potrf_scratch(np_, dev))
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError('K/sn2 + I not positive definite (pivot %d)' % int(info.item()))
+    Vt = W[np_ + r1:np_ + r1 + ns, :n]
+    kss = cov.getCovMatrix(z=xs, mode='self_test')
+    fs2 = kss - (Vt * Vt).sum(dim=1, keepdim=True)          # O(ns n) reduction
+    Fs2 = torch.clamp(fs2, min=0.)
+    # alpha^T = (L^-1 (f - m))^T L^-1 / sn2 : backward half on the reverse-transposed factor
+    Wt = torch.empty((np_, np_), dtype=torch.float64, device=dev)
+    ops.revt_lower(W, np_, Wt)
+    Rj = W[np_:np_ + r1].flip(1).contiguous()
+    ops.trsm_rows(Wt, np_, Rj, r1)
+    alphaT = (Rj.flip(1) / sn2).contiguous()                # (r1, np_), rows >= n_samples are zero
+    Fmu_full = torch.zeros((r2, r1), dtype=torch.float64, device=dev)
+    ops.gemm_nt(KsT, alphaT, Fmu_full, r2, r1, np_)          # Ks^T alpha
+    ms = model.meanfunc.getMean(xs)
+    Fmu = np.tile(ms, (1, n_samples)) + Fmu_full[:ns, :n_samples].cpu().numpy()
+    Fmu = np.mean(Fmu, axis=1, keepdims=True)
+    Fs2 = Fs2.cpu().numpy()
+    Ymu, Lower, Upper = model.likfunc.evaluate(mu=Fmu, s2=Fs2)
+    ym = np.reshape(np.mean(Ymu, axis=1), (ns, 1)) + my
+    ys_lw = np.reshape(np.mean(Lower, axis=1), (ns, 1)) + my
+    ys_up = np.reshape(np.mean(Upper, axis=1), (ns, 1)) + my
+    return ym, ys_lw, ys_up, Fs2

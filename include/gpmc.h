@@ -144,6 +144,11 @@ int gpmc_trmv_lower_f32(const float* W, int n, int ldw, const float* x, const fl
 int gpmc_trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, gpmc_stream_t stream);
 int gpmc_revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, gpmc_stream_t stream);
 
+/* ---- dense product for the predictive mean of inf_mcmc (np.dot(Ks.T, alpha), sliceSample.py:266) -----------------
+ * C (M x N, ldc) = A (M x K, lda) B^T (B: N x K, ldb); M, N multiples of 64, K multiple of 16.  f64, MFMA. */
+int gpmc_gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int M, int N, int K,
+                     gpmc_stream_t stream);
+
 /* ---- fused plan: one log-marginal evaluation per call -------------------------------------------
  * The metric's unit (a1 + a2 + a3 + a11): for hyper-parameters hyp (host, linear
  * scale: ell[1 or d], sf, sn) build K + S into the plan's workspace, factor it with g riding as an

@@ -121,6 +121,36 @@ def golden_trace(ref, out, name, n, d, iters, hyp0, seed, iter0=0):
     print('%s: n=%d iters=%d proposals=%d' % (name, n, iters, ntries.sum()))
 
 
+def golden_inf_mcmc(ref, out):
+    """the reference's own inf_mcmc (sliceSample.py:234-284) on a small model object"""
+    x, y = make_xy(60, 1, 77)
+    xs = np.linspace(-1., 11., 23).reshape(-1, 1)
+    rng = np.random.RandomState(8)
+    f = (y - y.mean())[:, None] + rng.standard_normal((60, 5))
+    hyp = np.array([1.1, 9.0, 1.3])
+    model = sds_ref.Model(x, y, xs, kcgp_ref.covK.RBF(np.log(hyp[0]), np.log(hyp[1])),
+                          kcgp_ref.likK.TruncatedGauss2(upper=100. - y.mean(), lower=0. - y.mean(),
+                                                        log_sigma=np.log(hyp[2])))
+    ym, lw, up, Fs2 = ref.inf_mcmc(f, model)
+    np.savez_compressed(os.path.join(out, 'inf_mcmc_n60.npz'), x=x, y=y, xs=xs, f=f, hyp=hyp, ym=ym, ys_lw=lw,
+                        ys_up=up, Fs2=Fs2)
+
+
+def golden_elliptical(ref, out):
+    """the reference's own elliptical_slice (sliceSample.py:15-74), seeded; nu recorded by re-deriving it"""
+    x, y = make_xy(40, 1, 55)
+    hyp = np.array([1.0, 10.0, 1.2])
+    f0 = (y - y.mean()) * 0.3
+    np.random.seed(31)
+    K = kcgp_ref.covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+    nu = np.random.multivariate_normal(np.zeros_like(f0), K, 1).T.reshape((40,))      # what the reference draws first
+    np.random.seed(31)
+    f1 = ref.elliptical_slice(f0.copy(), x, y, hyp)
+    tail = np.random.uniform(size=3)
+    np.savez_compressed(os.path.join(out, 'elliptical_n40.npz'), x=x, y=y, hyp=hyp, f0=f0, nu=nu, f1=f1, seed=31,
+                        rng_tail=tail)
+
+
 def golden_synthetic(out):
     """demoRegression.py:116-131 is Python-2-only __main__ code and cannot be executed;
     this fixture is the oracle's restatement of it (documented as such in the test)."""
@@ -141,6 +171,8 @@ def main():
     golden_trace(ref, a.out, 'trace_demo_n48_d2.npz', 48, 2, 10, sds_ref.DEMO_HYP0, 11)
     golden_trace(ref, a.out, 'trace_unfreeze_n8.npz', 8, 1, 520, sds_ref.FRAMEWORK_HYP0, 99)
     golden_trace(ref, a.out, 'trace_late_n32.npz', 32, 1, 8, sds_ref.FRAMEWORK_HYP0, 5, iter0=498)
+    golden_inf_mcmc(ref, a.out)
+    golden_elliptical(ref, a.out)
     golden_synthetic(a.out)
 
 

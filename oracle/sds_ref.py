@@ -243,3 +243,78 @@ def bench_inputs(n, d, seed=124, truth=(1.0, 10.0, 1.2), npoints=16, scale=(10.,
         lo = np.maximum(h - rng.uniform(0., s), 0.)
         pts.append(np.maximum(rng.uniform(lo, lo + s), 0.05))
     return X, g, np.asarray(pts)
+
+
+# --------------------------------------------------------------------------- "next" rows
+class ZeroMean(object):
+    def getMean(self, x):
+        return np.zeros((np.asarray(x).shape[0], 1))
+
+
+class ConstMean(object):
+    def __init__(self, c):
+        self.c = float(c)
+
+    def getMean(self, x):
+        return np.full((np.asarray(x).shape[0], 1), self.c)
+
+
+class Model(object):
+    """the attributes inf_mcmc reads from a kcGP.gpK.GPR instance (sliceSample.py:246-256,262-265,279)"""
+
+    def __init__(self, x, y, xs, covfunc, likfunc, meanfunc=None):
+        self.x, self.y, self.xs = x, y, xs
+        self.covfunc, self.likfunc = covfunc, likfunc
+        self.meanfunc = meanfunc or ZeroMean()
+
+
+def inf_mcmc(f, model, ys=0):
+    """Predictive fs|f at the test inputs -- sliceSample.py:234-284 restated (Cholesky branch, L upper)."""
+    x, y, xs = model.x, model.y, model.xs
+    my = np.mean(y)
+    n_samples = f.shape[1]
+    ns = xs.shape[0]
+    n = x.shape[0]
+    m = np.tile(model.meanfunc.getMean(x), (1, n_samples))
+    K = model.covfunc.getCovMatrix(x=x, mode='train')
+    sn2 = model.likfunc.sn ** 2.
+    L = tools.jitchol(K / sn2 + np.eye(n)).T
+    alpha = tools.solve_chol(L, f - m) / sn2
+    sW = np.ones((n, 1)) / np.sqrt(sn2)
+    kss = model.covfunc.getCovMatrix(z=xs, mode='self_test')
+    Ks = model.covfunc.getCovMatrix(x=x, z=xs, mode='cross')
+    ms = model.meanfunc.getMean(xs)
+    Fmu = np.tile(ms, (1, n_samples)) + np.dot(Ks.T, alpha)
+    V = scipy.linalg.solve_triangular(L.T, np.tile(sW, (1, ns)) * Ks, lower=True)
+    fs2 = kss - np.array([(V * V).sum(axis=0)]).T
+    Fs2 = np.maximum(fs2, 0)
+    Fmu = np.mean(Fmu, axis=1, keepdims=True)
+    Ymu, Lower, Upper = model.likfunc.evaluate(mu=Fmu, s2=Fs2)
+    ym = np.reshape(np.mean(Ymu, axis=1), (ns, 1)) + my
+    ys_lw = np.reshape(np.mean(Lower, axis=1), (ns, 1)) + my
+    ys_up = np.reshape(np.mean(Upper, axis=1), (ns, 1)) + my
+    return ym, ys_lw, ys_up, Fs2
+
+
+def elliptical_slice(f, x, y, hyp, nu=None):
+    """sliceSample.py:15-74.  nu ~ N(0, K): the reference draws it with multivariate_normal (SVD of K); with
+    ``nu`` given the rest is restated draw for draw (1 uniform for the height, 1 for theta, 1 per shrink)."""
+    nobs = f.shape[0]
+    my = np.mean(y)
+    if nu is None:
+        K = covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+        nu = np.random.multivariate_normal(np.zeros_like(f), K, 1).T.reshape((nobs,))
+    lik = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
+    cur_llk = lik.evaluate(y=y - my, mu=f) + np.log(np.random.uniform())
+    theta = np.random.uniform(high=2. * np.pi)
+    theta_min, theta_max = theta - 2. * np.pi, theta
+    while True:
+        prop_f = f * np.cos(theta) + nu * np.sin(theta)
+        prop_llk = lik.evaluate(y=y - my, mu=prop_f)
+        if prop_llk > cur_llk and np.isfinite(prop_llk):
+            return prop_f
+        if theta >= 0:
+            theta_max = theta
+        else:
+            theta_min = theta
+        theta = np.random.uniform(low=theta_min, high=theta_max)

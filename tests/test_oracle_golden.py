@@ -132,3 +132,28 @@ def test_matern_ard_limits():
     K = k.getCovMatrix(x=x, mode='train')
     assert np.allclose(np.diag(K), 2.25) and np.all(np.linalg.eigvalsh(K) > 0)
     assert np.allclose(K, K.T)
+
+
+def test_inf_mcmc_restatement_matches_reference(golden_dir):
+    """sliceSample.py:234-284 run by the reference itself (fixture) vs the oracle's restatement"""
+    from oracle.kcgp_ref import likK
+    z = _load(golden_dir, 'inf_mcmc_n60.npz')
+    hyp = z['hyp']
+    model = sds_ref.Model(z['x'], z['y'], z['xs'], covK.RBF(np.log(hyp[0]), np.log(hyp[1])),
+                          likK.TruncatedGauss2(upper=100. - z['y'].mean(), lower=0. - z['y'].mean(),
+                                               log_sigma=np.log(hyp[2])))
+    ym, lw, up, Fs2 = sds_ref.inf_mcmc(z['f'], model)
+    np.testing.assert_allclose(ym, z['ym'], rtol=1e-10)
+    np.testing.assert_allclose(lw, z['ys_lw'], rtol=1e-9)
+    np.testing.assert_allclose(up, z['ys_up'], rtol=1e-9)
+    np.testing.assert_allclose(Fs2, z['Fs2'], rtol=0, atol=1e-9 * np.abs(z['Fs2']).max())
+
+
+def test_elliptical_slice_restatement_matches_reference(golden_dir):
+    """sliceSample.py:15-74 run by the reference (seeded) vs the oracle restatement given the same nu"""
+    z = _load(golden_dir, 'elliptical_n40.npz')
+    np.random.seed(int(z['seed']))
+    f1 = sds_ref.elliptical_slice(z['f0'].copy(), z['x'], z['y'], z['hyp'])      # literal: draws nu itself
+    tail = np.random.uniform(size=3)
+    np.testing.assert_allclose(f1, z['f1'], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(tail, z['rng_tail'])
