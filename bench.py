@@ -79,11 +79,9 @@ def main():
     import gpmc
     from gpmc import _lib, chains, core
 
-    rank, world = chains.init_distributed()
-    local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the gpmc product path has no CPU fallback)')
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    rank, world = chains.init_distributed()          # binds cuda:LOCAL_RANK first, then joins the RCCL group
     dev = torch.device('cuda', torch.cuda.current_device())
 
     X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank)
@@ -92,7 +90,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -188,7 +186,7 @@ def main():
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[dev.index])
         dist.destroy_process_group()
 
 

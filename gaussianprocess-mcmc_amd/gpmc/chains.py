@@ -8,15 +8,30 @@ import torch
 import torch.distributed as dist
 
 
+def select_device():
+    """One process per GPU: bind this process to cuda:LOCAL_RANK BEFORE any process group exists (RCCL places its
+    communicator on the current device)."""
+    if not torch.cuda.is_available():
+        return None
+    local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    return torch.device('cuda', torch.cuda.current_device())
+
+
 def init_distributed(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for a single process."""
+    dev = select_device()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world == 1:
         return 0, 1
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        dist.init_process_group(backend=backend)
+            backend = 'nccl' if dev is not None else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group(backend=backend, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
 
@@ -42,8 +57,6 @@ def gather_histories(histHyp, histF=None, device=None):
 def run_chains(x, y, iters, hyp0, seed_base=124, gather_f=False, chain_fn=None):
     """Rank r runs chain r (legacy np.random seeded with seed_base + r) on its own GPU, then one gather."""
     rank, world = init_distributed()
-    if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1))
     np.random.seed(seed_base + rank)
     if chain_fn is None:
         from . import framework
