@@ -17,12 +17,13 @@ namespace gpmc {
 constexpr int G4_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
 
 template <int WGM, int WGN, int RG, int CG, bool EPI>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
                 double diag_add, int g_desync, int xmap) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
-    constexpr int NA = BM * 8 / 256, NBI = BN * 8 / 256;   // 16-byte chunks per thread per stage
+    constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
+    constexpr int NA = BM * 8 / NT, NBI = BN * 8 / NT;     // 16-byte chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem4[];
     char* As = smem4;                       // [2][BM][G4_ROWB]
     char* Bs = smem4 + 2 * BM * G4_ROWB;    // [2][BN][G4_ROWB]
@@ -115,26 +116,26 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
-            const int ch = tid + 256 * t;
+            const int ch = tid + NT * t;
             pa[t] = *reinterpret_cast<const d2_t*>(Ag + (size_t)(ch >> 3) * lda + k0 + (ch & 7) * 2);
         }
 #pragma unroll
         for (int t = 0; t < NBI; ++t) {
-            const int ch = tid + 256 * t;
+            const int ch = tid + NT * t;
             pb[t] = *reinterpret_cast<const d2_t*>(Bg + (size_t)(ch >> 3) * ldb + k0 + (ch & 7) * 2);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
-            const int ch = tid + 256 * t;
+            const int ch = tid + NT * t;
             d2_t v = pa[t];
             v[0] *= alpha; v[1] *= alpha;
             *reinterpret_cast<d2_t*>(As + ((size_t)buf * BM + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = v;
         }
 #pragma unroll
         for (int t = 0; t < NBI; ++t) {
-            const int ch = tid + 256 * t;
+            const int ch = tid + NT * t;
             *reinterpret_cast<d2_t*>(Bs + ((size_t)buf * BN + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = pb[t];
         }
     };

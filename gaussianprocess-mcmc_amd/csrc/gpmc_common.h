@@ -39,6 +39,8 @@ struct Options {
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
     int gemm_lds_pad = -1;    // -1 = auto (16000 under look-ahead, else 0)
+    int f32_nb = 256;         // outer block of the f32 factorisation for np_ >= 4096 (auto mode)
+    int gemm_8wave = 0;       // under look-ahead (GEMM at one workgroup per CU) use the 8-wave 128x128 variant
     int la_min_m = 3072;      // under look-ahead: switch to the serial schedule once fewer columns than this remain
     int gemm_lds_pad_unused = 0;     // extra dynamic LDS bytes requested by the big-tile GEMM (>= 14000 -> 1 workgroup per CU,
                               // leaving half of every CU to the look-ahead panel kernel)

@@ -19,6 +19,29 @@
 
 namespace gpmc {
 
+// storage <-> compute conversion: the panel arithmetic is always f64; TS (double or float) is what W holds
+template <typename TS>
+__device__ inline d2_t ld2(const TS* p);
+template <>
+__device__ inline d2_t ld2<double>(const double* p) { return *reinterpret_cast<const d2_t*>(p); }
+template <>
+__device__ inline d2_t ld2<float>(const float* p) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = *reinterpret_cast<const f2_t*>(p);
+    d2_t o; o[0] = (double)v[0]; o[1] = (double)v[1];
+    return o;
+}
+template <typename TS>
+__device__ inline void st2(TS* p, d2_t v);
+template <>
+__device__ inline void st2<double>(double* p, d2_t v) { *reinterpret_cast<d2_t*>(p) = v; }
+template <>
+__device__ inline void st2<float>(float* p, d2_t v) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t o; o[0] = (float)v[0]; o[1] = (float)v[1];
+    *reinterpret_cast<f2_t*>(p) = o;
+}
+
 struct PanelShared {
     // Ld: chunk of the diagonal strip's rows [row][k] (phase 1); the SAME storage then holds the diagonal
     // block's factor Lout (phases 2-3) -- 74 KB in all, so a panel workgroup fits on a CU beside one
@@ -38,9 +61,9 @@ struct PanelShared {
         if (DBG && blockIdx.x == 1 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();          \
     } while (0)
 
-template <bool DBG>
+template <bool DBG, typename TS>
 __global__ void __launch_bounds__(256)
-panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
+panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
                    double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char panel_smem[];
     PanelShared& sh = *reinterpret_cast<PanelShared*>(panel_smem);
@@ -55,8 +78,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         const double* src = lpark + (size_t)(prev_c0 / 64) * 4096;
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&W[((size_t)prev_c0 + row) * ld + prev_c0 + c2]) =
-                *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]);
+            st2<TS>(&W[((size_t)prev_c0 + row) * ld + prev_c0 + c2], *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]));
         }
     }
     double PD[4][4];
@@ -74,7 +96,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            Din[m][h] = (h <= m) ? W[((size_t)c0 + 4 * (w + 4 * m) + i) * ld + c0 + 16 * h + c] : 0.0;
+            Din[m][h] = (h <= m) ? (double)W[((size_t)c0 + 4 * (w + 4 * m) + i) * ld + c0 + 16 * h + c] : 0.0;
 
     PANEL_STAMP(1);
     // ---------------- 1. left-looking products over the K = c0 - k0 finished columns of this outer panel;
@@ -84,8 +106,8 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int e = tid + 256 * t, row = e >> 5, c2 = (e & 31) * 2;
-            pd[t] = *reinterpret_cast<const d2_t*>(&W[((size_t)c0 + row) * ld + kc + c2]);
-            if (!is_diag) ps[t] = *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + kc + c2]);
+            pd[t] = ld2<TS>(&W[((size_t)c0 + row) * ld + kc + c2]);
+            if (!is_diag) ps[t] = ld2<TS>(&W[(R0 + row) * ld + kc + c2]);
         }
     };
     if (k0 < c0) fetch_chunk(k0);
@@ -147,7 +169,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
         __syncthreads();
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = *reinterpret_cast<const d2_t*>(&W[(R0 + row) * ld + c0 + c2]);
+            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = ld2<TS>(&W[(R0 + row) * ld + c0 + c2]);
         }
         __syncthreads();
 #pragma unroll
@@ -215,7 +237,7 @@ panel_block_kernel(double* __restrict__ W, int ld, int k0, int c0, int* __restri
     __syncthreads();
     for (int e = tid; e < 64 * 32; e += 256) {
         const int row = e >> 5, c2 = (e & 31) * 2;
-        *reinterpret_cast<d2_t*>(&W[(R0 + row) * ld + c0 + c2]) = *reinterpret_cast<const d2_t*>(&sh.Ls[row][c2]);
+        st2<TS>(&W[(R0 + row) * ld + c0 + c2], *reinterpret_cast<const d2_t*>(&sh.Ls[row][c2]));
     }
     PANEL_STAMP(7);
 }
@@ -305,13 +327,13 @@ revt_lower_kernel(const double* __restrict__ L, int n, int ld, double* __restric
     }
 }
 
+template <typename TS>
 __global__ void __launch_bounds__(256)
-panel_flush_kernel(double* __restrict__ W, int ld, const double* __restrict__ lpark, int c0) {
+panel_flush_kernel(TS* __restrict__ W, int ld, const double* __restrict__ lpark, int c0) {
     const double* src = lpark + (size_t)(c0 / 64) * 4096;
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
         const int row = e >> 5, c2 = (e & 31) * 2;
-        *reinterpret_cast<d2_t*>(&W[((size_t)c0 + row) * ld + c0 + c2]) =
-            *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]);
+        st2<TS>(&W[((size_t)c0 + row) * ld + c0 + c2], *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]));
     }
 }
 

@@ -102,6 +102,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
     else if (!strcmp(name, "gemm_lds_pad")) g_opt.gemm_lds_pad = value;
     else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
+    else if (!strcmp(name, "gemm_8wave")) g_opt.gemm_8wave = value;
+    else if (!strcmp(name, "f32_nb")) g_opt.f32_nb = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -118,6 +120,8 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_xcd_map")) return g_opt.gemm_xcd_map;
     if (!strcmp(name, "gemm_lds_pad")) return g_opt.gemm_lds_pad;
     if (!strcmp(name, "la_min_m")) return g_opt.la_min_m;
+    if (!strcmp(name, "gemm_8wave")) return g_opt.gemm_8wave;
+    if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;
     return -1;
 }
 

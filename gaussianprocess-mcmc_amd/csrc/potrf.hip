@@ -323,6 +323,20 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
+            if (BM == 128 && g_lds_pad_now > 0 && g_opt.gemm_8wave) {
+                // look-ahead phase: one workgroup per CU -> make it 8 waves (2 per SIMD), wave tile 32 x 64
+                auto k8 = gemm4_nt_kernel<4, 2, 8, 4, EPI>;
+                static bool attr8_done = false;
+                if (!attr8_done) {
+                    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k8),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr8_done = true;
+                }
+                hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)g_lds_pad_now, s, A, lda, B, ldb, Cin, ldcin,
+                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0);
+                GPMC_LAUNCH_CHECK();
+                return 0;
+            }
             auto k4 = gemm4_nt_kernel<WGM, WGN, 4 * TM, TN, EPI>;
             static bool attr4_done = false;
             if (!attr4_done) {
@@ -430,17 +444,16 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
 // factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks
 template <typename T>
 static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s) {
-    if (sizeof(T) == 8 && g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns
-        static bool attr_done = false;
+    if (g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns (f64 arithmetic; W may be f32)
+        static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
-            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<false>),
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<false, T>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
             attr_done = true;
         }
         for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
-            hipLaunchKernelGGL(panel_block_kernel<false>, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
-                               reinterpret_cast<double*>(W), ld, k0, c0, info_dev, lpark, c0 - NB_IN,
-                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
+                               W, ld, k0, c0, info_dev, lpark, c0 - NB_IN, (unsigned long long*)nullptr);
             GPMC_LAUNCH_CHECK();
         }
         return 0;
@@ -486,19 +499,18 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
     T* dinv = reinterpret_cast<T*>(scratch);
     double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
-    const bool fused = (sizeof(T) == 8 && g_opt.panel_impl == 1);
+    const bool fused = (g_opt.panel_impl == 1);
     auto final_flush = [&]() -> int {
         if (!fused) return 0;
-        hipLaunchKernelGGL(panel_flush_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<double*>(W), ldw, lpark,
-                           np_ - NB_IN);
+        hipLaunchKernelGGL((panel_flush_kernel<T>), dim3(1), dim3(256), 0, s, W, ldw, lpark, np_ - NB_IN);
         GPMC_LAUNCH_CHECK();
         return 0;
     };
     // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k, the
     // GEMM held to one workgroup per CU so a panel workgroup always finds a slot) with NB = 256 for np_ >= 6144
-    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused) : (g_opt.lookahead != 0);
+    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused && sizeof(T) == 8) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
-    if (NB <= 0) NB = la ? 256 : 128;
+    if (NB <= 0) NB = la ? 256 : ((sizeof(T) == 4 && np_ >= 4096) ? g_opt.f32_nb : 128);
     if (NB < 128 || NB % 128) NB = 256;
     g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? 16000 : 0) : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
@@ -625,10 +637,10 @@ int gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, i
 // diagnostic: run the DBG instantiation of the panel kernel once on (W, k0, c0) and return 8 s_memtime stamps
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
                        unsigned long long* dbg_dev, hipStream_t s) {
-    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true>),
+    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true, double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
-    hipLaunchKernelGGL(panel_block_kernel<true>, dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W, ld, k0,
-                       c0, info_dev, lpark, -1, dbg_dev);
+    hipLaunchKernelGGL((panel_block_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W,
+                       ld, k0, c0, info_dev, lpark, -1, dbg_dev);
     GPMC_LAUNCH_CHECK();
     return 0;
 }

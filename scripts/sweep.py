@@ -57,6 +57,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--w8']:
+        for w8 in (0, 1, 0, 1):
+            gpmc.set_option('gemm_8wave', w8)
+            print('gemm_8wave', w8)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--tail']:
         for lm in (0, 3072, 4096, 5120, 6144, 7168):
             gpmc.set_option('la_min_m', lm)
