@@ -26,63 +26,87 @@ __device__ inline double mp_readlane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// sqrt(d) and 1/sqrt(d): v_rsq_f64 seed + 2 Goldschmidt iterations (no division, no denormal fix-up path)
-__device__ inline void mp_sqrt_rsqrt(double d, double& sq, double& rs) {
+// 1/sqrt(d): v_rsq_f64 seed + Goldschmidt refinement (no division, no denormal fix-up path).  MP_RSQ_ITERS = 2
+// is accurate to ~1 ulp; 1 iteration is selectable for measurement (-DMP_RSQ_ITERS=1).
+#ifndef MP_RSQ_ITERS
+#define MP_RSQ_ITERS 2
+#endif
+__device__ inline double mp_rsqrt(double d) {
     const double y = __builtin_amdgcn_rsq(d);
     double g = d * y, h = 0.5 * y;
     double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
+#if MP_RSQ_ITERS >= 2
+    g = __builtin_fma(g, r, g);
     r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    sq = g;
-    rs = h + h;
+#endif
+    return h + h;
 }
 
 // Slabs of wave w: D[m][h], m = 0..3 (slab row g = w + 4m), h = 0..m.
 // One micro-step, T8 compile-time.  All 256 threads call; two barriers inside.
+// dbgp != nullptr only in the diagnostic instantiation (stamps of micro-step 3 by every wave's lane 0)
+#define MP_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if (T8 == 3 && dbgp != nullptr && lane == 0) dbgp[8 + 8 * w + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 template <int T8>
 __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
-                                     double* rsd, int w, int lane, int gcol) {
+                                     double* rsd, int w, int lane, int gcol, unsigned long long* dbgp = nullptr) {
     constexpr int HT = T8 >> 1;            // slab column that holds columns 8T8..8T8+7
     constexpr int CLO = 8 * (T8 & 1);      // first lane-column of the micro-panel inside that slab
     const int i = lane >> 4, c = lane & 15;
+    MP_STAMP(0);
     // ---- 1. extract columns 8T8..8T8+7, rows >= 8T8
 #pragma unroll
     for (int m = HT; m < 4; ++m) {
         const int g = w + 4 * m;
         if (4 * g + 3 >= 8 * T8 && (c >> 3) == (T8 & 1)) Praw[4 * g + i][c - CLO] = D[m][HT];
     }
+    MP_STAMP(1);
     __syncthreads();
+    MP_STAMP(2);
     // ---- 2. wave 0: factor the micro-panel, lane = row
     if (w == 0) {
         const int row = lane;
-        double p[8];
+        double p[8], rsv[8];
+        int bad = 0;                                         // wave-uniform: 1-based first non-positive pivot
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[k] = Praw[row][k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int pr = 8 * T8 + k;                       // pivot row == pivot column
             const double d = mp_readlane(p[k], pr);
-            if (!(d > 0.0) && lane == 0 && *failp == 0) *failp = gcol + pr + 1;
-            double sq, rs;
-            mp_sqrt_rsqrt(d, sq, rs);
-            if (lane == 0) rsd[pr] = rs;                     // 1 / L[pr][pr], reused by the 4x4 inverses
-            double lk = p[k] * rs;
-            lk = (row == pr) ? sq : lk;
-            lk = (row < pr) ? 0.0 : lk;
+            bad = (bad == 0 && !(d > 0.0)) ? (pr + 1) : bad;
+            const double rs = mp_rsqrt(d);
+            rsv[k] = rs;
+            const double lk = p[k] * rs;                     // row pr: d * rs = sqrt(d) to ~1 ulp; rows above: junk, zeroed below
             p[k] = lk;
+            // right-looking: the 7-k independent rank-1 updates issue back to back; only p[k+1]'s is on the pivot
+            // chain.  The empty asm pins this order (hipcc otherwise sinks all k updates of column k in front of
+            // pivot k as one dependent FMA chain).
 #pragma unroll
             for (int k2 = k + 1; k2 < 8; ++k2) {
                 const double mlt = mp_readlane(lk, 8 * T8 + k2);   // L[8T8+k2][8T8+k]
                 p[k2] = __builtin_fma(-lk, mlt, p[k2]);
+                asm volatile("" : "+v"(p[k2]));
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) Lout[row][8 * T8 + k] = p[k];
+        for (int k = 0; k < 8; ++k) Lout[row][8 * T8 + k] = (row < 8 * T8 + k) ? 0.0 : p[k];
+        if (lane < 8) {
+            double rsel = rsv[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) rsel = (lane == k) ? rsv[k] : rsel;
+            rsd[8 * T8 + lane] = rsel;                       // 1 / L[j][j], reused by the 4x4 inverses
+        }
+        if (lane == 0 && bad != 0 && *failp == 0) *failp = gcol + bad;
     }
+    MP_STAMP(3);
     __syncthreads();
+    MP_STAMP(4);
     // ---- 3. rank-8 update of the slabs below / right of the micro-panel
     if (T8 < 7) {
         const int ka = lane >> 4, ia = lane & 3;             // A operand: lane (k, blk, i)
@@ -104,18 +128,19 @@ __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], d
             }
         }
     }
+    MP_STAMP(5);
 }
 
 // Factor the block held in slabs; on return Lout holds L (strict upper zero).  gcol = global column of the block.
 __device__ inline void mp_factor64(double (&D)[4][4], double (*Lout)[MP_LD], double (*Praw)[MP_PLD], int* failp,
-                                   double* rsd, int tid, int gcol) {
+                                   double* rsd, int tid, int gcol, unsigned long long* dbgp = nullptr) {
     const int w = tid >> 6, lane = tid & 63;
     if (tid == 0) *failp = 0;
     __syncthreads();
     mp_micro_step<0>(D, Lout, Praw, failp, rsd, w, lane, gcol);
     mp_micro_step<1>(D, Lout, Praw, failp, rsd, w, lane, gcol);
     mp_micro_step<2>(D, Lout, Praw, failp, rsd, w, lane, gcol);
-    mp_micro_step<3>(D, Lout, Praw, failp, rsd, w, lane, gcol);
+    mp_micro_step<3>(D, Lout, Praw, failp, rsd, w, lane, gcol, dbgp);
     mp_micro_step<4>(D, Lout, Praw, failp, rsd, w, lane, gcol);
     mp_micro_step<5>(D, Lout, Praw, failp, rsd, w, lane, gcol);
     mp_micro_step<6>(D, Lout, Praw, failp, rsd, w, lane, gcol);

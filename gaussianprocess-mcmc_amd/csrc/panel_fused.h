@@ -179,7 +179,7 @@ panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__
     PANEL_STAMP(3);
     // ---------------- 2. factor the diagonal block (every workgroup); Ld is dead from here on
     __syncthreads();
-    mp_factor64(D, Lout, sh.Praw, &sh.fail, sh.rsd, tid, c0);
+    mp_factor64(D, Lout, sh.Praw, &sh.fail, sh.rsd, tid, c0, (DBG && blockIdx.x == 1) ? dbg : nullptr);
 
     PANEL_STAMP(4);
     if (is_diag) {
