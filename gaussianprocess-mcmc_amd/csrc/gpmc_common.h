@@ -47,7 +47,8 @@ struct Options {
     int gemm_xcd_map = 0;     // 1: XCD-aware 8x8 super-block tile order in the 4x4x4 GEMM
     int gemm_desync = 0;      // 1: alternate dispatch waves fold C in after the K loop (breaks the lock-step)
     int gemm_impl = 1;        // 1: v_mfma_f64_4x4x4 slab GEMM (f64), 0: v_mfma_*_16x16x4 GEMM
-    int panel_impl = 1;       // 1: fused update+factor+TRSM kernel per 64 columns (f64), 0: three kernels
+    int panel_impl = 1;       // 1: fused kernel (4 waves, default); 2: fused kernel with in-block look-ahead (5 waves; measured
+                              // +-0.5 %: the workers become the long pole); 0: three kernels
     int diag_impl = 3;        // 0: LDS column loop, 1: single wave, 2: register-blocked VALU, 3: micro-panel + MFMA 4x4x4
 };
 extern Options g_opt;

@@ -24,6 +24,7 @@
 #include "diag_rb.h"
 #include "diag_mp.h"
 #include "panel_fused.h"
+#include "panel_fused2.h"
 #include "gemm4.h"
 
 namespace gpmc {
@@ -444,6 +445,20 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
 // factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks
 template <typename T>
 static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s) {
+    if (g_opt.panel_impl == 2) {   // fused kernel with in-block look-ahead: 5 waves, wave 4 = serial micro-panel factor
+        static bool attr2_done = false;   // per T instantiation
+        if (!attr2_done) {
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block2_kernel<false, T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panel2Shared)));
+            attr2_done = true;
+        }
+        for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
+            hipLaunchKernelGGL((panel_block2_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(320), sizeof(Panel2Shared),
+                               s, W, ld, k0, c0, info_dev, lpark, c0 - NB_IN, (unsigned long long*)nullptr);
+            GPMC_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     if (g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns (f64 arithmetic; W may be f32)
         static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
@@ -499,7 +514,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
     T* dinv = reinterpret_cast<T*>(scratch);
     double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
-    const bool fused = (g_opt.panel_impl == 1);
+    const bool fused = (g_opt.panel_impl >= 1);
     auto final_flush = [&]() -> int {
         if (!fused) return 0;
         hipLaunchKernelGGL((panel_flush_kernel<T>), dim3(1), dim3(256), 0, s, W, ldw, lpark, np_ - NB_IN);
@@ -637,6 +652,14 @@ int gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, i
 // diagnostic: run the DBG instantiation of the panel kernel once on (W, k0, c0) and return 8 s_memtime stamps
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
                        unsigned long long* dbg_dev, hipStream_t s) {
+    if (g_opt.panel_impl == 2) {
+        GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block2_kernel<true, double>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panel2Shared)));
+        hipLaunchKernelGGL((panel_block2_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(320), sizeof(Panel2Shared),
+                           s, W, ld, k0, c0, info_dev, lpark, -1, dbg_dev);
+        GPMC_LAUNCH_CHECK();
+        return 0;
+    }
     GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true, double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
     hipLaunchKernelGGL((panel_block_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W,

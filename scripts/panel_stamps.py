@@ -11,7 +11,7 @@ lib = _lib.lib()
 fn = lib.gpmc_debug_panel_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-dbg = torch.zeros(48, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(64, dtype=torch.int64, device='cuda')
 names = ['start->loads issued', 'K loop', 'D/T form (incl. strip LDS transpose)', 'factor (mp_factor64)', 'to inverses', 'inverses',
          'TRSM', 'store']
 for k0, c0 in ((0, 0), (0, 64), (0, 128), (0, 192)):
@@ -25,7 +25,7 @@ for k0, c0 in ((0, 0), (0, 64), (0, 128), (0, 192)):
     d = np.diff(t)
     print('K=%3d total %6d ticks: ' % (c0 - k0, t[7] - t[0]) + '  '.join('%s=%d' % (nm.split(' ')[0], x) for nm, x in zip(names[:7], d)))
     if c0 == 0:
-        for w in range(4):
-            tw = tall[8 + 8 * w: 8 + 8 * w + 6]
-            print('   micro-step 3, wave %d: extract=%d  wait B1=%d  factor(w0)=%d  wait B2=%d  update=%d   (start %d)' % ((w,) + tuple(np.diff(tw)) + (tw[0] - tall[8],)))
+        for w in range(5):
+            tw = tall[8 + 8 * w: 8 + 8 * w + 5]
+            print('   micro-step 3, wave %d: pre-B1 work=%d  wait B1=%d  factor/shadow work=%d  wait B2=%d   (start %d)' % ((w,) + tuple(np.diff(tw)) + (tw[0] - tall[8],)))
 print('(s_memtime ticks; 100 MHz reference => 1 tick = 10 ns if constant-rate, else shader cycles)')

@@ -57,6 +57,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--panel']:
+        for pi in (1, 2, 1, 2):
+            gpmc.set_option('panel_impl', pi)
+            print('panel_impl', pi)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--w8']:
         for w8 in (0, 1, 0, 1):
             gpmc.set_option('gemm_8wave', w8)

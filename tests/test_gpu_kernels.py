@@ -204,3 +204,38 @@ def test_solve_chol_matches_oracle(gp, n, m):
     np.testing.assert_allclose(A @ X, B, rtol=0, atol=1e-9 * np.abs(B).max() * np.linalg.cond(A) ** 0.5)
     v = gp['tools'].solve_chol(U, B[:, 0]).cpu().numpy()
     np.testing.assert_allclose(v, Xref[:, 0], rtol=0, atol=1e-9 * np.abs(Xref).max())
+
+
+def test_jitchol_f32_storage(gp):
+    """float32 matrices go through the same fused panel kernel (f64 panel arithmetic, f32 storage and trailing MFMA)"""
+    n = 700
+    A = _spd(n, 21, cond=1e3)
+    L = gp['tools'].jitchol(torch.as_tensor(A, dtype=torch.float32).cuda())
+    assert L.dtype == torch.float32
+    Ln = L.cpu().numpy().astype(np.float64)
+    assert np.all(np.triu(Ln, 1) == 0)
+    res = np.abs(Ln @ Ln.T - A).max() / np.abs(A).max()
+    assert res < 5e-6, res
+
+
+def test_panel_and_gemm_variants_agree(gp):
+    """the alternative kernels kept behind options compute the same factorisation (bitwise for schedule-only options,
+    to rounding for different kernels)"""
+    n = 1500
+    x, g = _x(n, 2, 3), np.random.RandomState(4).standard_normal(n)
+    hyp = [1.0, 10.0, 1.2]
+    gpmc = gp['gpmc']
+    ref = sds_ref.gp_log_marginal(x, g, hyp)
+    vals = {}
+    try:
+        for name, opts in (('default', {}), ('panel2', {'panel_impl': 2}), ('three-kernel', {'panel_impl': 0}),
+                           ('gemm16', {'gemm_impl': 0}), ('diag_wave', {'panel_impl': 0, 'diag_impl': 1}),
+                           ('diag_rb', {'panel_impl': 0, 'diag_impl': 2})):
+            for k, v in opts.items():
+                gpmc.set_option(k, v)
+            vals[name] = gp['core'].log_marginal(x, g, hyp)
+            gpmc.set_option('panel_impl', 1), gpmc.set_option('gemm_impl', 1), gpmc.set_option('diag_impl', 3)
+    finally:
+        gpmc.set_option('panel_impl', 1), gpmc.set_option('gemm_impl', 1), gpmc.set_option('diag_impl', 3)
+    for name, v in vals.items():
+        assert abs(v - ref) <= 1e-10 * abs(ref), (name, v, ref)
