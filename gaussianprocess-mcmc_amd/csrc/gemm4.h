@@ -102,7 +102,10 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) acc[rg][cg] = Cin[(size_t)(crow + 4 * rg) * ldcin + ccol + 16 * cg];
+            for (int cg = 0; cg < CG; ++cg) {
+                const double* cp = &Cin[(size_t)(crow + 4 * rg) * ldcin + ccol + 16 * cg];
+                acc[rg][cg] = (g_desync & 16) ? __builtin_nontemporal_load(cp) : *cp;   // bit 4: streaming C tiles
+            }
     } else {
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
@@ -182,7 +185,8 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
                 if (gr == gc) v += diag_add;
                 if (gr >= n_true || gc >= n_true) v = (gr == gc) ? 1.0 : 0.0;
             }
-            C[(size_t)gr * ldc + gc] = v;
+            if (g_desync & 16) __builtin_nontemporal_store(v, &C[(size_t)gr * ldc + gc]);
+            else C[(size_t)gr * ldc + gc] = v;
         }
 }
 
