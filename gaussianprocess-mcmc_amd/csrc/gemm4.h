@@ -14,19 +14,24 @@
 
 namespace gpmc {
 
-constexpr int G4_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
+constexpr int G4_ROWB = 144;  // LDS bytes per tile row at KCH = 2: 128 data + 16 pad (KCH = 4: 256 + 16)
 
-template <int WGM, int WGN, int RG, int CG, bool EPI>
+// KCH = number of 8-k chunks per LDS stage (2 -> BK = 16, 4 -> BK = 32).  The small-tile configuration uses 4: its
+// workgroups are latency-bound (one global round trip per stage for ~0.3 us of MFMA work), so fewer, fatter stages.
+template <int WGM, int WGN, int RG, int CG, bool EPI, int KCH = 2>
 __global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
                 double diag_add, int g_desync, int xmap) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
-    constexpr int NA = BM * 8 / NT, NBI = BN * 8 / NT;     // 16-byte chunks per thread per stage
+    constexpr int BKE = 8 * KCH;                           // k elements per stage
+    constexpr int CPR = 4 * KCH;                           // 16-byte chunks per tile row
+    constexpr int ROWB = 64 * KCH + 16;                    // LDS bytes per tile row
+    constexpr int NA = BM * CPR / NT, NBI = BN * CPR / NT; // 16-byte chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem4[];
     char* As = smem4;                       // [2][BM][G4_ROWB]
-    char* Bs = smem4 + 2 * BM * G4_ROWB;    // [2][BN][G4_ROWB]
+    char* Bs = smem4 + 2 * BM * ROWB;       // [2][BN][ROWB]
 
     int ti, tj;
     if (xmap) {
@@ -120,12 +125,12 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
             const int ch = tid + NT * t;
-            pa[t] = *reinterpret_cast<const d2_t*>(Ag + (size_t)(ch >> 3) * lda + k0 + (ch & 7) * 2);
+            pa[t] = *reinterpret_cast<const d2_t*>(Ag + (size_t)(ch / CPR) * lda + k0 + (ch % CPR) * 2);
         }
 #pragma unroll
         for (int t = 0; t < NBI; ++t) {
             const int ch = tid + NT * t;
-            pb[t] = *reinterpret_cast<const d2_t*>(Bg + (size_t)(ch >> 3) * ldb + k0 + (ch & 7) * 2);
+            pb[t] = *reinterpret_cast<const d2_t*>(Bg + (size_t)(ch / CPR) * ldb + k0 + (ch % CPR) * 2);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -134,33 +139,33 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
             const int ch = tid + NT * t;
             d2_t v = pa[t];
             v[0] *= alpha; v[1] *= alpha;
-            *reinterpret_cast<d2_t*>(As + ((size_t)buf * BM + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = v;
+            *reinterpret_cast<d2_t*>(As + ((size_t)buf * BM + (ch / CPR)) * ROWB + (ch % CPR) * 16) = v;
         }
 #pragma unroll
         for (int t = 0; t < NBI; ++t) {
             const int ch = tid + NT * t;
-            *reinterpret_cast<d2_t*>(Bs + ((size_t)buf * BN + (ch >> 3)) * G4_ROWB + (ch & 7) * 16) = pb[t];
+            *reinterpret_cast<d2_t*>(Bs + ((size_t)buf * BN + (ch / CPR)) * ROWB + (ch % CPR) * 16) = pb[t];
         }
     };
 
-    const int nk = K / 16;
+    const int nk = K / BKE;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * 16);
+        if (kt + 1 < nk) load_tiles((kt + 1) * BKE);
         // A: lane (k = l>>4, blk, i = l&3) reads row 4rg+i ; B: lane (k = l>>4, col = l&15) reads row 16cg+col
-        const char* Ab = As + ((size_t)cur * BM + wm * RG * 4 + ia) * G4_ROWB + i * 16;
-        const char* Bb = Bs + ((size_t)cur * BN + wn * CG * 16 + c) * G4_ROWB + i * 16;
+        const char* Ab = As + ((size_t)cur * BM + wm * RG * 4 + ia) * ROWB + i * 16;
+        const char* Bb = Bs + ((size_t)cur * BN + wn * CG * 16 + c) * ROWB + i * 16;
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
+        for (int kc = 0; kc < KCH; ++kc) {
             d2_t bf[CG];
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) bf[cg] = *reinterpret_cast<const d2_t*>(Bb + cg * 16 * G4_ROWB + kc * 64);
+            for (int cg = 0; cg < CG; ++cg) bf[cg] = *reinterpret_cast<const d2_t*>(Bb + cg * 16 * ROWB + kc * 64);
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
-                const d2_t af = *reinterpret_cast<const d2_t*>(Ab + rg * 4 * G4_ROWB + kc * 64);
+                const d2_t af = *reinterpret_cast<const d2_t*>(Ab + rg * 4 * ROWB + kc * 64);
                 // the two k-halves of one accumulator are issued CG instructions apart (no back-to-back dependence)
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg)

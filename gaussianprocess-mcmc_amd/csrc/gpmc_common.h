@@ -39,6 +39,8 @@ struct Options {
     int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
     int gemm_lds_pad = -1;    // -1 = auto (16000 under look-ahead, else 0)
+    int gemm_persistent = 0;  // big-tile f64 trailing update: persistent 8-wave kernel with C-tile prefetch (gemm4p.h)
+    int gemm_small_bk32 = 0;  // small-tile (64x64) f64 GEMM: 32 k per LDS stage instead of 16
     int f32_nb = 256;         // outer block of the f32 factorisation for np_ >= 4096 (auto mode)
     int gemm_8wave = 0;       // under look-ahead (GEMM at one workgroup per CU) use the 8-wave 128x128 variant
     int la_min_m = 3072;      // under look-ahead: switch to the serial schedule once fewer columns than this remain

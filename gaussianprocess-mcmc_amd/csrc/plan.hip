@@ -104,6 +104,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
     else if (!strcmp(name, "gemm_8wave")) g_opt.gemm_8wave = value;
     else if (!strcmp(name, "f32_nb")) g_opt.f32_nb = value;
+    else if (!strcmp(name, "gemm_small_bk32")) g_opt.gemm_small_bk32 = value;
+    else if (!strcmp(name, "gemm_persistent")) g_opt.gemm_persistent = value;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -122,6 +124,8 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "la_min_m")) return g_opt.la_min_m;
     if (!strcmp(name, "gemm_8wave")) return g_opt.gemm_8wave;
     if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;
+    if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;
+    if (!strcmp(name, "gemm_persistent")) return g_opt.gemm_persistent;
     return -1;
 }
 

@@ -26,6 +26,7 @@
 #include "panel_fused.h"
 #include "panel_fused2.h"
 #include "gemm4.h"
+#include "gemm4p.h"
 
 namespace gpmc {
 
@@ -324,6 +325,22 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
+            if (BM == 128 && beta && g_opt.gemm_persistent && g_lds_pad_now == 0 && nblk >= 64) {
+                // persistent pipelined kernel: one 512-thread workgroup per CU walks the tile list, next C tile
+                // prefetched under the current K loop
+                auto kp = gemm4p_nt_kernel<EPI>;
+                static bool attrp_done = false;
+                if (!attrp_done) {
+                    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attrp_done = true;
+                }
+                const int gridp = nblk < 256 ? nblk : 256;
+                hipLaunchKernelGGL(kp, dim3(gridp), dim3(512), smem + 16384, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc,
+                                   tri, nblk, alpha, n_true, diag_add);
+                GPMC_LAUNCH_CHECK();
+                return 0;
+            }
             if (BM == 128 && g_lds_pad_now > 0 && g_opt.gemm_8wave) {
                 // look-ahead phase: one workgroup per CU -> make it 8 waves (2 per SIMD), wave tile 32 x 64
                 auto k8 = gemm4_nt_kernel<4, 2, 8, 4, EPI>;
@@ -335,6 +352,20 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 }
                 hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)g_lds_pad_now, s, A, lda, B, ldb, Cin, ldcin,
                                    C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0);
+                GPMC_LAUNCH_CHECK();
+                return 0;
+            }
+            if (BM == 64 && g_opt.gemm_small_bk32 && K % 32 == 0) {   // small tiles: BK = 32 (half the stages)
+                auto ks = gemm4_nt_kernel<WGM, WGN, 4 * TM, TN, EPI, 4>;
+                const size_t smems = (size_t)2 * (BM + BN) * (64 * 4 + 16);
+                static bool attrs_done = false;
+                if (!attrs_done) {
+                    GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ks),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attrs_done = true;
+                }
+                hipLaunchKernelGGL(ks, dim3(nblk), dim3(256), smems, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
+                                   alpha, beta, n_true, diag_add, 0, 0);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }

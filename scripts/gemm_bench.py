@@ -9,8 +9,8 @@ np_ = 8192
 for kp in (128, 256, 1024):
     P = torch.randn((np_, kp), dtype=torch.float64, device='cuda')
     C = torch.randn((np_, np_), dtype=torch.float64, device='cuda')
-    for gi, ds in ((1, 0), (1, 16), (1, 0), (1, 16)):
-        gpmc.set_option('gemm_impl', gi), gpmc.set_option('gemm_desync', ds)
+    for gi, ds in ((1, 0), (1, 1), (1, 0), (1, 1)):
+        gpmc.set_option('gemm_impl', gi), gpmc.set_option('gemm_persistent', ds)
         ops.syrk_diff(C, P, kp, C, np_, np_, 0.0)
         torch.cuda.synchronize()
         reps = 5 if kp >= 1024 else 20
@@ -20,4 +20,4 @@ for kp in (128, 256, 1024):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         tiles = 64 * 65 // 2
-        print('kp=%5d gemm_impl=%d nt_flag=%d: %8.3f ms  tile-flops %.1f TF/s' % (kp, gi, ds, dt * 1e3, tiles * 128 * 128 * kp * 2 / dt / 1e12), flush=True)
+        print('kp=%5d gemm_impl=%d persistent=%d: %8.3f ms  tile-flops %.1f TF/s' % (kp, gi, ds, dt * 1e3, tiles * 128 * 128 * kp * 2 / dt / 1e12), flush=True)

@@ -57,6 +57,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--bk']:
+        for v in (0, 1, 0, 1):
+            gpmc.set_option('gemm_small_bk32', v)
+            print('gemm_small_bk32', v)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--panel']:
         for pi in (1, 2, 1, 2):
             gpmc.set_option('panel_impl', pi)
