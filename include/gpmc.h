@@ -171,6 +171,8 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
 /* device pointer / geometry of the factored workspace of the last evaluation (for callers that go on
  * to use L): W, mp, np_, ld */
 int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
+/* synchronises the plan's stream and releases the plan.  The workspace and stream passed to gpmc_plan_create must
+ * still be valid: retiring the captured launch graph replays the last evaluation once (see plan.hip). */
 int gpmc_plan_destroy(gpmc_plan* p);
 
 /* instrumentation of the dominant kernel (the trailing SYRK update of gpmc_potrf): between begin and read every

@@ -57,6 +57,13 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--nbla']:
+        for nb, lm in ((256, 3072), (384, 3072), (512, 3072), (384, 4608), (512, 4096), (512, 5120), (256, 3072)):
+            gpmc.set_option('outer_nb', nb), gpmc.set_option('lookahead', 1), gpmc.set_option('la_min_m', lm)
+            print('outer_nb', nb, 'la_min_m', lm)
+            for a in sys.argv[2:]:
+                one(int(a))
+        return
     if sys.argv[1:2] == ['--bk']:
         for v in (0, 1, 0, 1):
             gpmc.set_option('gemm_small_bk32', v)
