@@ -43,6 +43,26 @@ def synth_inputs(n, d, seed=124, truth=(1.0, 10.0, 1.2), npoints=16, scale=(10.,
     return X, g, np.asarray(pts)
 
 
+def pmc_traffic(n, kernel_prefix='gpmc::gemm4_nt_kernel'):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes over this same
+    command (profiles/r*_bench_n<N>_pmc.json, written by scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled for gfx950, KB -> B); launch-weighted mean over the kernel's tile variants.
+    Counters cannot be collected from inside the timed process, hence the committed file; None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_n%d_pmc.json' % n)))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        doc = json.load(fh)
+    num = den = 0.0
+    for name, e in doc.get('kernels', {}).items():
+        if name.startswith(kernel_prefix) and 'hbm_bytes_per_launch' in e:
+            w = 0.5 * (e['launches_fetch_pass'] + e['launches_write_pass'])
+            num += w * e['hbm_bytes_per_launch']
+            den += w
+    return (num / den if den else None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(X, g, pts, budget_s=20.0):
     """B-lean of BASELINE.md: the oracle's SciPy path (cdist+exp, dpotrf, dtrsv) on the host cores, bounded sample."""
     from oracle import sds_ref
@@ -160,6 +180,7 @@ def main():
     if rank == 0:
         value = world * a.steps / tmax
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(a.n) if a.d == 2 else (None, None)
         line = {
             'metric': 'GP log-marginal evals/sec (= slice-sample steps/sec) at N=%d' % a.n,
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -178,7 +199,8 @@ def main():
                          'whole_step_tflops': (a.n ** 3 / 3.0) / (tmax / a.steps) / 1e12,
                          'measured_in': 'second pass over the same steps, eager launches, HIP events on the launch stream',
                          'ms_per_step_instrumented': 1e3 * dt_instr / a.steps,
-                         'traffic': None},
+                         'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (PMC)',
+                         'traffic_source': traffic_src},
             'cpu_baseline': cpu,
         }
         if extra:
