@@ -108,9 +108,14 @@ def main():
     # timed region: the plan's default path (the per-evaluation launch sequence replayed as a hipGraph)
     plan = core.LogMarginalPlan(X, g, 'rbf')
 
+    nccl = world > 1 and dist.get_backend() == 'nccl'
+
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[dev.index])
+            if nccl:
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -146,7 +151,7 @@ def main():
     dt_instr = time.perf_counter() - t1
     k_ms, k_launches, k_flops = _lib.profile_read()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or world == 1) else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
@@ -208,7 +213,7 @@ def main():
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
-        dist.barrier(device_ids=[dev.index])
+        barrier()
         dist.destroy_process_group()
 
 

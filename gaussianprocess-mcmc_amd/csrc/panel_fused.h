@@ -44,15 +44,21 @@ __device__ inline void st2<float>(float* p, d2_t v) {
 
 struct PanelShared {
     // Ld: chunk of the diagonal strip's rows [row][k] (phase 1); the SAME storage then holds the diagonal
-    // block's factor Lout (phases 2-3) -- 74 KB in all, so a panel workgroup fits on a CU beside one
-    // 74 KB GEMM workgroup and the look-ahead really overlaps.
+    // block's factor Lout (phases 2-3).  78,856 B in all.  LDS budget of the look-ahead: a CU has 163,840 B; the
+    // big-tile GEMM asks for 73,728 B + a pad that lifts it above 81,920 B (so two of them never share a CU) yet
+    // leaves room for one of these (potrf.hip, g_lds_pad_now) -- with 1,280-byte allocation granules 62 + 65 <= 128.
+    // Before Linv was folded onto Praw the struct was 80,904 B (64 granules) and the two kernels never shared a CU:
+    // every panel launch waited for GEMM workgroups to retire.
     double Ld[64][MP_LD];
     double Ls[64][MP_LD];     // chunk of this strip's rows; later the strip block in / out
-    double Praw[64][MP_PLD];
-    double Linv[16][4][4];    // inverses of the 4x4 diagonal blocks of Lout
+    union {
+        double Praw[64][MP_PLD];  // micro-panel staging of the factor (dead after mp_factor64's closing barrier)
+        double Linv[16][4][4];    // inverses of the 4x4 diagonal blocks of Lout (written after that barrier)
+    };
     double rsd[64];           // 1 / L[j][j] from the micro-panel wave
     int fail;
 };
+static_assert(sizeof(PanelShared) <= 62 * 1280, "PanelShared must stay within 62 LDS granules (see the budget above)");
 
 // DBG = true is a diagnostic instantiation only (gpmc_debug_panel_stamps): wave 0 of workgroup 1 writes s_memtime
 // stamps at the phase boundaries into dbg[]; the production launch uses DBG = false and no stamp executes.
@@ -64,7 +70,10 @@ struct PanelShared {
 template <bool DBG, typename TS>
 __global__ void __launch_bounds__(256)
 panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
-                   double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg) {
+                   double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg, int hi_prio) {
+    // Beside the trailing GEMM (look-ahead) every SIMD also holds a GEMM wave issuing MFMAs back to back; this
+    // kernel is a latency chain, so its waves ask for issue priority.
+    if (hi_prio) __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char panel_smem[];
     PanelShared& sh = *reinterpret_cast<PanelShared*>(panel_smem);
     double (*Lout)[MP_LD] = sh.Ld;   // aliased: valid once phase 1 is over

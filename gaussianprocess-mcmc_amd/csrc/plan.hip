@@ -121,6 +121,9 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
     else if (!strcmp(name, "gemm_lds_pad")) g_opt.gemm_lds_pad = value;
     else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
+    else if (!strcmp(name, "panel_prio")) g_opt.panel_prio = value ? 1 : 0;
+    else if (!strcmp(name, "la_order")) g_opt.la_order = value ? 1 : 0;
+    else if (!strcmp(name, "la_depth")) g_opt.la_depth = (value == 2) ? 2 : 1;
     else if (!strcmp(name, "gemm_8wave")) g_opt.gemm_8wave = value;
     else if (!strcmp(name, "f32_nb")) g_opt.f32_nb = value;
     else if (!strcmp(name, "gemm_small_bk32")) g_opt.gemm_small_bk32 = value;
@@ -141,6 +144,9 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_xcd_map")) return g_opt.gemm_xcd_map;
     if (!strcmp(name, "gemm_lds_pad")) return g_opt.gemm_lds_pad;
     if (!strcmp(name, "la_min_m")) return g_opt.la_min_m;
+    if (!strcmp(name, "la_depth")) return g_opt.la_depth;
+    if (!strcmp(name, "la_order")) return g_opt.la_order;
+    if (!strcmp(name, "panel_prio")) return g_opt.panel_prio;
     if (!strcmp(name, "gemm_8wave")) return g_opt.gemm_8wave;
     if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;
     if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;

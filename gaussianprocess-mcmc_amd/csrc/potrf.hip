@@ -499,7 +499,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
         }
         for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
             hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
-                               W, ld, k0, c0, info_dev, lpark, c0 - NB_IN, (unsigned long long*)nullptr);
+                               W, ld, k0, c0, info_dev, lpark, c0 - NB_IN, (unsigned long long*)nullptr, g_opt.panel_prio);
             GPMC_LAUNCH_CHECK();
         }
         return 0;
@@ -591,7 +591,65 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     }
     hipStream_t ps = ax->panel_stream;
     int evi = 0;
-    auto next_ev = [&]() { hipEvent_t e = ax->ev[evi]; evi = (evi + 1) % 8; return e; };
+    auto next_ev = [&]() { hipEvent_t e = ax->ev[evi]; evi = (evi + 1) % 16; return e; };
+    if (g_opt.la_depth == 2) {
+        // ---- depth-2 look-ahead.  With c_k = k NB:
+        //   panel stream : P_0 | U_1 P_1 | U_2 P_2 | ...   U_{k+1} = columns [c_{k+1}, c_{k+2}) -= panel k (small tiles),
+        //                                                  P_{k+1} = factor those columns
+        //   main stream  : G_0 | G_1 | G_2 | ...           G_k = columns [c_{k+2}, np_) -= panel k (big tiles)
+        // G_k waits for P_k; U_{k+1} waits for G_{k-1} (which brought its columns up to panel k-1).  The main stream
+        // then carries nothing but the big GEMMs back to back: the latency-bound next-panel update and one
+        // cross-stream hand-over per step leave its critical path.
+        hipEvent_t pe_prev, ge_prev = nullptr;
+        {
+            hipEvent_t ef = next_ev();   // fork: the panel stream starts behind whatever built the matrix on s
+            GPMC_HIP(hipEventRecord(ef, s));
+            GPMC_HIP(hipStreamWaitEvent(ps, ef, 0));
+            const int nbk = (np_ < NB) ? np_ : NB;
+            int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, lpark, ps);
+            if (rc) return rc;
+            pe_prev = next_ev();
+            GPMC_HIP(hipEventRecord(pe_prev, ps));
+        }
+        for (int k0 = 0; k0 < np_; k0 += NB) {
+            const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
+            const int k1 = k0 + nbk;
+            if (k1 >= np_) {   // panel k was the last one: join
+                GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
+                break;
+            }
+            if (np_ - k1 < g_opt.la_min_m) {
+                // tail: join, bring the whole remaining matrix up to panel k, continue serially with NB = 128
+                GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
+                g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
+                int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+                if (rc) return rc;
+                rc = serial_from(k1, 128);
+                if (rc) return rc;
+                return final_flush();
+            }
+            const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;
+            const int k2 = k1 + nbn;
+            // panel stream: U_{k+1}, P_{k+1}
+            if (ge_prev) GPMC_HIP(hipStreamWaitEvent(ps, ge_prev, 0));
+            int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, ps, k1, k2, true);
+            if (rc) return rc;
+            rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
+            if (rc) return rc;
+            hipEvent_t pe_next = next_ev();
+            GPMC_HIP(hipEventRecord(pe_next, ps));
+            // main stream: G_k
+            GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
+            if (k2 < np_) {
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k2, np_);
+                if (rc) return rc;
+                ge_prev = next_ev();
+                GPMC_HIP(hipEventRecord(ge_prev, s));
+            }
+            pe_prev = pe_next;
+        }
+        return final_flush();
+    }
     // panel 0 on the main stream
     {
         const int nbk = (np_ < NB) ? np_ : NB;
@@ -617,6 +675,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (rc) return rc;
         hipEvent_t e1 = next_ev();
         GPMC_HIP(hipEventRecord(e1, s));
+        // Enqueue order matters under graph replay: the runtime keeps a node's first-added successor on the same
+        // hardware queue and sends later-added ones across (~11 us per crossing, measured from the kernel trace).
+        // la_order = 1 issues (3) before (2), so the main-stream chain (1) -> (3) -> (1') stays on one queue and
+        // the crossings move to the panel chain, which has slack.
+        if (g_opt.la_order == 1 && k1 + nbn < np_) {
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1 + nbn, np_);
+            if (rc) return rc;
+        }
         // (2) factor next panel on ps
         GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
         rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
@@ -624,7 +690,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         hipEvent_t e2 = next_ev();
         GPMC_HIP(hipEventRecord(e2, ps));
         // (3) the rest of the trailing matrix, on s, concurrently with (2)
-        if (k1 + nbn < np_) {
+        if (g_opt.la_order != 1 && k1 + nbn < np_) {
             rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1 + nbn, np_);
             if (rc) return rc;
         }
@@ -694,7 +760,7 @@ int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev,
     GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true, double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
     hipLaunchKernelGGL((panel_block_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W,
-                       ld, k0, c0, info_dev, lpark, -1, dbg_dev);
+                       ld, k0, c0, info_dev, lpark, -1, dbg_dev, 0);
     GPMC_LAUNCH_CHECK();
     return 0;
 }

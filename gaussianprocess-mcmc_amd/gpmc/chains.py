@@ -25,8 +25,8 @@ def init_distributed(backend=None):
     if world == 1:
         return 0, 1
     if not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if dev is not None else 'gloo'
+        if backend is None:   # GPMC_DIST_BACKEND=gloo: rehearse several ranks on one GPU (RCCL wants one device per rank)
+            backend = os.environ.get('GPMC_DIST_BACKEND') or ('nccl' if dev is not None else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group(backend=backend, device_id=dev)

@@ -57,6 +57,38 @@ def main():
             for a in sys.argv[2:]:
                 one(int(a))
         return
+    if sys.argv[1:2] == ['--pad']:
+        # LDS request of the big-tile GEMM under look-ahead: 73,728 B + pad.  > 81,920 B keeps it to one workgroup per
+        # CU; <= 163,840 - 80,904 (PanelShared) = 82,936 B lets a panel workgroup share the CU.
+        for pad, prio in ((16000, 0), (0, 0), (0, 1), (16000, 1), (9216, 1), (16000, 0)):
+            gpmc.set_option('gemm_lds_pad', pad), gpmc.set_option('panel_prio', prio), gpmc.set_option('lookahead', 1)
+            gpmc.set_option('outer_nb', 256)
+            print('gemm_lds_pad', pad, 'panel_prio', prio)
+            for a in sys.argv[2:]:
+                one(int(a), 10)
+        return
+    if sys.argv[1:2] == ['--prio']:
+        for prio, depth, lam in ((0, 1, 3072), (1, 1, 3072), (1, 1, 2048), (1, 1, 1024), (1, 2, 3072), (1, 2, 2048), (0, 1, 3072)):
+            gpmc.set_option('panel_prio', prio), gpmc.set_option('la_depth', depth), gpmc.set_option('la_min_m', lam)
+            print('panel_prio', prio, 'la_depth', depth, 'la_min_m', lam)
+            for a in sys.argv[2:]:
+                one(int(a), 10)
+        return
+    if sys.argv[1:2] == ['--depth']:
+        # look-ahead depth 1 vs 2 (potrf.hip) across the tail switch point; value printed for a parity eyeball
+        for depth, lam, nb in ((1, 3072, 0), (2, 3072, 0), (2, 2048, 0), (2, 4096, 0), (2, 1024, 0), (2, 3072, 384), (1, 3072, 0)):
+            gpmc.set_option('la_depth', depth), gpmc.set_option('la_min_m', lam), gpmc.set_option('outer_nb', nb)
+            print('la_depth', depth, 'la_min_m', lam, 'outer_nb', nb)
+            for a in sys.argv[2:]:
+                n = int(a)
+                rng = np.random.RandomState(124)
+                X = rng.uniform(0, 10, (n, 2)); g = rng.standard_normal(n) * 5
+                plan = core.LogMarginalPlan(X, g, 'rbf')
+                v = plan([1.0, 10.0, 1.2])
+                dt = time_plan(plan, [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0]], 10)
+                print('  n=%d: %.3f ms/eval   logml %.9f' % (n, dt * 1e3, v), flush=True)
+                plan.close()
+        return
     if sys.argv[1:2] == ['--nbla']:
         for nb, lm in ((256, 3072), (384, 3072), (512, 3072), (384, 4608), (512, 4096), (512, 5120), (256, 3072)):
             gpmc.set_option('outer_nb', nb), gpmc.set_option('lookahead', 1), gpmc.set_option('la_min_m', lm)
