@@ -7,7 +7,11 @@ BASELINE.json's metric is quoted on: RBF kernel, N = 8192, d = 2, fp64, syntheti
 the host.  Evaluations are issued back to back on one stream with distinct hyper-parameters cycled from 16
 points drawn from the sampler's bracket; nothing is cached between steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--sds]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--no-sds] [--sds-cpu]
+
+Besides the metric, rank 0 reports in "extra" the rate of FULL surrogate-data-slice proposals (SURVEY.md 8(a) a1-a11:
+K, chol(K+S), V = L^-1 K, R = K - V^T V, m, chol R, f', log-marginal) on the same inputs; --sds-cpu also times ONE
+proposal in the reference's literal op sequence on the host (oracle restatement; about a minute at N=8192).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs its own independent chain-shaped
 stream of evaluations on its own GPU (weak scaling, no data-path collective); rank 0 prints ONE JSON line with
@@ -91,7 +95,8 @@ def main():
     ap.add_argument('--n', type=int, default=8192)
     ap.add_argument('--d', type=int, default=2)
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--sds', action='store_true', help='also time full SDS proposals (reported in the "extra" field)')
+    ap.add_argument('--no-sds', action='store_true', help='skip the full-SDS-proposal rate in "extra"')
+    ap.add_argument('--sds-cpu', action='store_true', help='also time one literal reference-sequence proposal on the host')
     a = ap.parse_args()
 
     import torch
@@ -166,7 +171,7 @@ def main():
                 raise SystemExit('parity failure vs SciPy at point %d: %r vs %r' % (j, got, v))
 
     extra = {}
-    if a.sds and rank == 0:
+    if not a.no_sds and rank == 0:
         from gpmc import sds
         ws = sds.SDSWorkspace(X)
         f = torch.zeros(a.n, dtype=torch.float64, device=dev)
@@ -181,6 +186,19 @@ def main():
             ws.propose_f(eta).cpu()
         torch.cuda.synchronize()
         extra['sds_proposals_per_s'] = reps / (time.perf_counter() - t1)
+        extra['sds_flops_per_proposal'] = 8.0 * a.n ** 3 / 3.0
+        del ws
+        if a.sds_cpu:
+            # the reference's literal op sequence (sliceSample.py:136-147,165-207) through the oracle restatement
+            from oracle import sds_ref
+            from oracle.kcgp_ref import covK as ref_covK
+            h = pts[0]
+            t1 = time.perf_counter()
+            Kc = ref_covK.RBF(np.log(h[0]), np.log(h[1])).getCovMatrix(x=X, mode='train')
+            _, K_S, m_, C_, L_ = sds_ref.aux_var_model_literal(np.zeros(a.n), Kc, h[2], g)
+            _ = np.dot(C_, eta.cpu().numpy()) + m_
+            _ = sds_ref.log_marginal_literal(g, K_S, L_)
+            extra['sds_cpu_literal_s_per_proposal'] = time.perf_counter() - t1
 
     if rank == 0:
         value = world * a.steps / tmax

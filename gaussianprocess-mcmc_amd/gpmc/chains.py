@@ -54,6 +54,23 @@ def gather_histories(histHyp, histF=None, device=None):
     return out[0], out[1]
 
 
+def gather_vector(v):
+    """Each rank holds a float vector with NaN where it has no result; one all_gather, then the non-NaN entry per
+    slot (every slot is owned by exactly one rank) -> the full vector on every rank."""
+    v = np.asarray(v, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return v
+    device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.as_tensor(v).to(device)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    allv = torch.stack(bufs).cpu().numpy()
+    have = ~np.isnan(allv)
+    if np.any(have.sum(axis=0) > 1):
+        raise RuntimeError('gather_vector: a slot was filled by more than one rank')
+    return np.where(have.any(axis=0), np.nansum(allv, axis=0), np.nan)
+
+
 def run_chains(x, y, iters, hyp0, seed_base=124, gather_f=False, chain_fn=None):
     """Rank r runs chain r (legacy np.random seeded with seed_base + r) on its own GPU, then one gather."""
     rank, world = init_distributed()

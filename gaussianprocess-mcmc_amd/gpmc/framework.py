@@ -31,17 +31,186 @@ def run_chain(x, y, iters, hyp0, scale=SCALE, iter0=0, verbose=False, workspace=
 
 
 class Framework(object):
-    """data: ndarray (n, 1 + d) = [target | inputs] as at framework.py:24-28."""
+    """data: ndarray (n, 1 + d) = [target | inputs] as at framework.py:24-28; ``window`` / ``gap`` are accepted and
+    ignored by the base class exactly as there."""
 
-    def __init__(self, data):
+    def __init__(self, data, window=None, gap=None):
         if data is None:
             raise Exception('No data is given.')
         self.x = data[:, 1:]
         self.y = np.reshape(data[:, 0], (np.shape(data)[0], 1))
+        self.verbose = False
+        self.setScaleOpt(None)
+
+    def execute(self):
+        pass
+
+    def setScaleOpt(self, scale):
+        """framework.py:39-41 (the reference prints the option; here only when ``self.verbose``)."""
+        self.scaleOpt = scale
+        if self.verbose:
+            print('Current data scaling option: %s' % (self.scaleOpt))
+
+    def getScaleData(self):
+        """framework.py:43-57: 'ctr' -> y - mean, 'std' -> (y - mean) / std (population std), else unchanged."""
+        avg = np.mean(self.y, 0)
+        stdev = np.std(self.y, 0)
+        if self.scaleOpt == 'ctr':
+            self.y = self.y - avg
+        elif self.scaleOpt == 'std':
+            self.y = (self.y - avg) / stdev
 
     def runSimulMCMC(self, iters, verbose=False):
-        histF, histHyp, _ = run_chain(self.x, self.y.reshape(-1), iters, FRAMEWORK_HYP0, verbose=verbose)
+        histF, histHyp, _ = run_chain(self.x, np.asarray(self.y).reshape(-1), iters, FRAMEWORK_HYP0, verbose=verbose)
         return histF, histHyp
+
+    def output(self, gap=0, histHyp=None, histF=None, llk=None, outdir='./output'):
+        """framework.py:79-122 (``fGap`` assumes 1-D inputs like the reference: x is reshaped to one column)."""
+        return output(self.x, self.y, gap, histHyp, histF, llk, outdir)
+
+    def getFoldData(self, fold, gap, window):
+        """framework.py:124-147 -> train_x, train_y, test_x, test_y, test_id.
+
+        Test ids are ``fold + [0, gap) + (gap + window) * i`` for ``i < n // (gap + window)`` (Python-2 ``/`` on ints);
+        everything else trains; ids past the end of the data are dropped after the training set is formed (the
+        NumPy 1.12 ``np.delete`` of the reference ignored them)."""
+        n = self.x.shape[0]
+        test_id = []
+        for i in range(n // (gap + window)):
+            test_id = np.append(test_id, fold + np.arange(gap) + (gap + window) * i)
+        test_id = np.asarray(test_id, dtype=np.int64)
+        keep = np.ones(n, dtype=bool)
+        keep[test_id[(test_id >= 0) & (test_id < n)]] = False
+        train_id = np.nonzero(keep)[0]
+        test_id = test_id[test_id < n]
+        return self.x[train_id, :], self.y[train_id, 0], self.x[test_id, :], self.y[test_id, 0], test_id
+
+
+class singleRun(Framework):
+    """First framework: single-run GP (framework.py:149-175).  ``updOpt='mcmcSml'`` runs the chain and writes the CSVs;
+    ``'opt'`` is kcGP.gpK.GPR.optimize, which is out of scope."""
+
+    def __init__(self, data):
+        super(singleRun, self).__init__(data, window=None, gap=None)
+        self.name = 'First framework: single-run GP'
+
+    def execute(self, updOpt=None, iterMCMC=1000, outdir='./output'):
+        self.getScaleData()
+        assert updOpt is not None, 'Please choose either optimization or MCMC'
+        if updOpt == 'opt':
+            raise NotImplementedError("updOpt='opt' (GPR.optimize) is outside the MCMC path this package replaces")
+        if updOpt == 'mcmcSml':
+            histF, histHyp = self.runSimulMCMC(iterMCMC)
+            self.output(histHyp=histHyp.T, histF=histF, outdir=outdir)
+            return histF, histHyp
+
+
+def fold_owner(task, world):
+    """(gap, fold) task number -> rank: round robin, the chain-per-GPU launcher of SURVEY.md 8(f) rank 4."""
+    return task % world
+
+
+def selected_samples(iters):
+    """framework.py:225 (Python-2 integer division)."""
+    return list(range(iters * 9 // 10 - 1, iters, 10))
+
+
+class crossValid(Framework):
+    """Second framework: GP with cross validation over (gap, fold) (framework.py:177-248).
+
+    Every fold is an independent chain plus a handful of ``inf_mcmc`` predictives, so folds are the shard: with a
+    process group of ``world`` ranks (one per GPU) task t = (gap, fold) in enumeration order runs on rank
+    ``t % world``; ONE all_gather of the per-fold log-likelihoods ends ``execute`` (no data-path collective).
+
+    Random stream: a single process consumes the global legacy ``np.random`` stream fold after fold exactly like the
+    reference.  With more than one rank (or ``seed_base`` given) fold t is seeded ``seed_base + t`` so the result does
+    not depend on the partition.
+
+    ``pairing='literal'`` evaluates ``trunclik.evaluate(y=ys, mu=valY, s2=fs2)/ys.shape[0]`` as written at
+    framework.py:246 -- ys is (ns, 1) and valY (ns,), which NumPy broadcasts to all ns x ns pairs; ``'matched'`` pairs
+    prediction i with target i.  TruncatedGauss2 is inferred (likK.py), so these numbers are parity-unpinned.
+    """
+
+    def __init__(self, data, window, gapArray):
+        super(crossValid, self).__init__(data, window, gapArray)
+        self.name = 'Second framework: GP with window width: %d' % (window)
+        self.windowSize = window
+        self.gapArray = gapArray
+        self.testLLK = {}
+
+    def foldLLK(self, x, y, valX, valY, foldF, foldHyp, iterMCMC, pairing='literal'):
+        """framework.py:221-246 for one fold (x, y = the fold's training data)."""
+        from . import covK, gpK, likK
+        model = gpK.GPR()
+        model.xs = valX
+        upper = 100. - np.mean(y)
+        lower = 0. - np.mean(y)
+        out = []
+        for i in selected_samples(iterMCMC):
+            ll, sf, sn = foldHyp[0, i], foldHyp[1, i], foldHyp[2, i]
+            propF = foldF[:, i].reshape((foldF.shape[0], 1))
+            model.setPrior(kernel=covK.RBF(np.log(ll), np.log(sf)))
+            model.setNoise(np.log(sn))
+            model.setData(x, y)
+            trunclik = likK.TruncatedGauss2(upper=upper, lower=lower, log_sigma=np.log(sn))
+            model.likfunc = trunclik
+            ys, _, _, fs2 = sliceSample.inf_mcmc(propF, model)          # inference fs|f
+            trunclik.upper = 100.
+            trunclik.lower = 0.
+            if pairing == 'literal':
+                out.append(trunclik.evaluate(y=ys, mu=valY, s2=fs2) / ys.shape[0])
+            else:
+                out.append(trunclik.evaluate(y=ys.reshape(-1), mu=valY, s2=np.asarray(fs2).reshape(-1)) / ys.shape[0])
+        return float(np.mean(out))
+
+    def runFold(self, gap, fold, iterMCMC, pairing='literal'):
+        """One (gap, fold) task on this process's GPU -> (llk, foldF, foldHyp); self.x / self.y are left on the
+        fold's training data like the reference does."""
+        self.x, self.y = self._originalX, self._originalY
+        self.x, self.y, valX, valY, _ = self.getFoldData(fold, gap, window=self.windowSize)
+        foldF, foldHyp = self.runSimulMCMC(iterMCMC)
+        return self.foldLLK(self.x, self.y, valX, valY, foldF, foldHyp, iterMCMC, pairing), foldF, foldHyp
+
+    def execute(self, updOpt=None, iterMCMC=1000, pairing='literal', seed_base=None, outdir='./output', fold_fn=None):
+        """-> {gap: [llk per fold]} on every rank (also kept in ``self.testLLK``); rank 0 writes the reference's
+        CSVs per gap (hyper-parameter / latent histories of the last fold IT ran, like the reference's last fold).
+        ``fold_fn(gap, fold, iterMCMC) -> (llk, foldF, foldHyp)`` replaces ``runFold`` (used by the CPU tests of the
+        fan-out)."""
+        import torch.distributed as dist
+        assert updOpt is not None, 'Please choose either optimization or MCMC'
+        if updOpt == 'opt':
+            raise NotImplementedError("updOpt='opt' (GPR.optimize) is outside the MCMC path this package replaces")
+        self.getScaleData()
+        self._originalX, self._originalY = self.x[:], self.y[:]
+        rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+        if world > 1 and seed_base is None:
+            seed_base = 124
+        run = fold_fn or (lambda g, f, it: self.runFold(g, f, it, pairing))
+        tasks = [(gap, fold) for gap in self.gapArray for fold in range(gap + self.windowSize)]
+        llk = np.full(len(tasks), np.nan)
+        last = {}
+        for t, (gap, fold) in enumerate(tasks):
+            if fold_owner(t, world) != rank:
+                continue
+            if seed_base is not None:
+                np.random.seed(seed_base + t)
+            if self.verbose:
+                print('Gap: %r, fold %d' % (gap, fold + 1))
+            llk[t], foldF, foldHyp = run(gap, fold, iterMCMC)
+            last[gap] = (foldF, foldHyp, self.x, self.y)      # the reference writes the gap's last fold with ITS x, y
+        if world > 1:
+            from . import chains
+            llk = chains.gather_vector(llk)           # the one collective: every rank gets every fold's number
+        res, t = {}, 0
+        for gap in self.gapArray:
+            nf = gap + self.windowSize
+            res[gap] = [float(v) for v in llk[t:t + nf]]
+            t += nf
+            if rank == 0 and outdir is not None and gap in last:
+                foldF, foldHyp, fx, fy = last[gap]
+                output(fx, fy, gap, foldHyp.T, foldF, res[gap], outdir)
+        self.testLLK = res
+        return res
 
 
 def mcmcUpdate(data, n_samples, ll=0.35, sf=2.0, sn=0.2, verbose=False):

@@ -44,6 +44,19 @@ def workspace_for(x):
     return ws
 
 
+MAX_SHRINK = 10000      # safety net only: a bracket of width 10 collapses to one double after ~60 halvings
+_ZERO_LIK_MSG = ('the current state has zero likelihood under the truncated noise model: some target lies outside '
+                 '[%g, %g] - mean(y) (e.g. centred or standardised targets); no proposal can ever be accepted and '
+                 "the reference's `while True` would never return")
+
+
+def _check_finite_start(cur_llk):
+    """Deviation from the reference, on purpose: with a non-finite current log-likelihood its `while True`
+    (sliceSample.py:129-163, :59-74) can never accept and never returns; fail loudly instead of spinning."""
+    if not np.isfinite(cur_llk):
+        raise ValueError(_ZERO_LIK_MSG % (Y_LOWER, Y_UPPER))
+
+
 def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=None):
     ws = workspace or workspace_for(x)
     y = np.asarray(y, dtype=np.float64).reshape(-1)
@@ -70,6 +83,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
 
     lik_func = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
     cur_llk = lik_func.evaluate(y=y - my, mu=f_host)
+    _check_finite_start(cur_llk)
 
     prior, _ = log_gamma(hyp, PRIOR_K, PRIOR_THETA, True)
     threshold = np.log(np.random.uniform()) + cur_llk + prior[1] + prior[0] + curG
@@ -78,6 +92,8 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
 
     ntry = 0
     while True:
+        if ntry >= MAX_SHRINK:
+            raise RuntimeError('surrogate_slice_sampling: no acceptable proposal after %d shrink steps' % ntry)
         ntry += 1
         prop_hyp = np.random.uniform(low=hyp_min, high=hyp_max)
         if iter < NOISE_FREEZE_ITERS:
@@ -123,7 +139,9 @@ def elliptical_slice(f, x, y, hyp, nu=None):
         ops.trmv_lower(L, nobs, z, None, nu_d)
         nu = nu_d.cpu().numpy()
     lik_func = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
-    cur_llk = lik_func.evaluate(y=y - my, mu=f) + np.log(np.random.uniform())
+    cur_llk = lik_func.evaluate(y=y - my, mu=f)
+    _check_finite_start(cur_llk)
+    cur_llk = cur_llk + np.log(np.random.uniform())
     theta = np.random.uniform(high=2. * np.pi)
     theta_min, theta_max = theta - 2. * np.pi, theta
     while True:

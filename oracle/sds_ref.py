@@ -132,6 +132,14 @@ def gp_log_marginal(x, g, hyp, kernel='rbf'):
 
 
 # --------------------------------------------------------------------------- sampler
+def _check_finite_start(cur_llk):
+    """NOT in the reference: with a non-finite current log-likelihood (a target outside the truncation bounds, e.g.
+    centred targets) its `while True` loops (sliceSample.py:59-74,129-163) never accept and never return.  The
+    restatement raises instead so that a test cannot hang; the product raises the same error."""
+    if not np.isfinite(cur_llk):
+        raise ValueError('current state has zero likelihood under the truncated noise model; the sampler cannot move')
+
+
 def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=None):
     """One SDS update of (f, hyp) -- sliceSample.py:76-163, draw for draw.
 
@@ -154,6 +162,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=No
 
     lik = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
     cur_llk = lik.evaluate(y=y - my, mu=f)
+    _check_finite_start(cur_llk)
     curG = log_marginal_literal(g, K_S, L) if literal else log_marginal_lean(g, L)
 
     prior, _ = log_gamma(hyp, PRIOR_K, PRIOR_THETA, True)
@@ -305,7 +314,9 @@ def elliptical_slice(f, x, y, hyp, nu=None):
         K = covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
         nu = np.random.multivariate_normal(np.zeros_like(f), K, 1).T.reshape((nobs,))
     lik = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
-    cur_llk = lik.evaluate(y=y - my, mu=f) + np.log(np.random.uniform())
+    cur_llk = lik.evaluate(y=y - my, mu=f)
+    _check_finite_start(cur_llk)
+    cur_llk = cur_llk + np.log(np.random.uniform())
     theta = np.random.uniform(high=2. * np.pi)
     theta_min, theta_max = theta - 2. * np.pi, theta
     while True:

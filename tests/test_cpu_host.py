@@ -113,3 +113,97 @@ def test_single_process_gather_is_identity():
     h = np.arange(12.).reshape(3, 4)
     a, b = chains.gather_histories(h, None)
     assert a.shape == (1, 3, 4) and b is None and np.array_equal(a[0], h)
+
+
+# ----------------------------------------------------------------------- cross-validation harness
+def _cv_data(n=53, seed=0):
+    rng = np.random.RandomState(seed)
+    return np.hstack([rng.uniform(0, 100, (n, 1)), np.arange(float(n)).reshape(-1, 1)])
+
+
+def test_get_fold_data_matches_oracle_and_partitions_the_data():
+    """framework.py:124-147: train / test split per (fold, gap, window), including folds whose last test ids run past
+    the data and window sizes for which no test id exists at all."""
+    from gpmc import framework
+    from oracle import framework_ref as fr
+    for n in (53, 60, 7):
+        F = framework.Framework(_cv_data(n))
+        for gap, win in ((2, 4), (3, 5), (1, 1), (5, 2), (7, 50), (4, 0)):
+            for fold in range(gap + win):
+                a = F.getFoldData(fold, gap, win)
+                b = fr.get_fold_data(F.x, F.y, fold, gap, win)
+                for u, v in zip(a, b):
+                    np.testing.assert_array_equal(u, v)
+                tr_x, tr_y, te_x, te_y, te_id = a
+                assert tr_y.ndim == 1 and te_y.ndim == 1 and tr_x.shape == (len(tr_y), 1)
+                assert len(tr_y) + len(np.unique(te_id)) == n                 # every point is train xor test
+                assert np.array_equal(te_x[:, 0], te_id.astype(float))        # x = arange(n) here
+                if n // (gap + win) > 0 and gap > 0:
+                    assert te_id[0] == fold                                   # first masked block starts at `fold`
+    F = framework.Framework(_cv_data(60))
+    _, _, _, _, te = F.getFoldData(5, 2, 4)           # the fifth and last fold of gap 2 / window 4: ids 5,6, 11,12, ...
+    assert list(te[:4]) == [5, 6, 11, 12] and te.max() == 59 and len(te) == 19          # id 60 falls off the end
+
+
+def test_scale_options_and_selected_samples():
+    from gpmc import framework
+    from oracle import framework_ref as fr
+    d = _cv_data(40, seed=3)
+    for opt in (None, 'ctr', 'std'):
+        F = framework.Framework(d)
+        F.setScaleOpt(opt)
+        F.getScaleData()
+        np.testing.assert_array_equal(F.y, fr.scale_data(d[:, :1], opt))
+    assert abs(F.y.mean()) < 1e-12 and abs(F.y.std() - 1.0) < 1e-12
+    assert framework.selected_samples(1000) == list(range(899, 1000, 10)) == fr.selected_samples(1000)
+    assert framework.selected_samples(30) == [26] and framework.selected_samples(20) == [17]
+    with pytest.raises(Exception):
+        framework.Framework(None)
+    with pytest.raises(NotImplementedError):
+        framework.crossValid(d, 4, [2]).execute(updOpt='opt')
+
+
+_CV_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, 'gaussianprocess-mcmc_amd'))
+from gpmc import chains, framework
+
+rank, world = chains.init_distributed()
+rng = np.random.RandomState(0)
+data = np.hstack([rng.uniform(0, 100, (53, 1)), np.arange(53.).reshape(-1, 1)])
+ran = []
+
+def fake_fold(gap, fold, iters):
+    # stands in for chain + predictive on the GPU: a number that depends on the fold's seeded stream only
+    ran.append((gap, fold))
+    return float(np.random.uniform()) + 10 * gap + fold, np.zeros((53, iters)), np.zeros((3, iters))
+
+cv = framework.crossValid(data, 4, [2, 3])
+res = cv.execute(updOpt='mcmcSml', iterMCMC=5, fold_fn=fake_fold, outdir=%(out)r)
+tasks = [(g, f) for g in (2, 3) for f in range(g + 4)]
+assert ran == [t for i, t in enumerate(tasks) if i %% world == rank], ran      # round-robin shard, in order
+for i, (g, f) in enumerate(tasks):
+    np.random.seed(124 + i)
+    want = float(np.random.uniform()) + 10 * g + f
+    assert res[g][f] == want, (g, f, res[g][f], want)
+assert sorted(res) == [2, 3] and len(res[2]) == 6 and len(res[3]) == 7
+print('rank', rank, 'ok')
+'''
+
+
+def test_cross_valid_fold_fanout_world_size_2_gloo(tmp_path):
+    """(gap, fold) tasks are dealt round robin to ranks, seeded per task, and ONE all_gather returns every fold's
+    number to every rank; rank 0 writes llkGap<gap>.csv in the reference's layout (gloo, CPU, no GPU compute)."""
+    script = tmp_path / 'cv_worker.py'
+    out = tmp_path / 'out'
+    script.write_text(_CV_WORKER % {'root': ROOT, 'out': str(out)})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('ok') == 2
+    rows = (out / 'llkGap3.csv').read_text().strip().splitlines()
+    assert rows[0] == 'gap,0,1,2,3,4,5,6' and rows[1].startswith('3,') and len(rows[1].split(',')) == 8
+    assert (out / 'hypGap2.csv').read_text().splitlines()[0] == 'll,sf2,sn'

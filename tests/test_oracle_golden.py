@@ -157,3 +157,16 @@ def test_elliptical_slice_restatement_matches_reference(golden_dir):
     tail = np.random.uniform(size=3)
     np.testing.assert_allclose(f1, z['f1'], rtol=0, atol=1e-10)
     np.testing.assert_array_equal(tail, z['rng_tail'])
+
+
+def test_oracle_refuses_a_zero_likelihood_start():
+    """guard added to the restatement (not in the reference): centred targets fall outside the truncation bounds, the
+    reference would spin forever in its `while True`; the oracle raises so no test can hang on it"""
+    rng = np.random.RandomState(0)
+    x = np.arange(12.).reshape(-1, 1)
+    y = rng.uniform(10, 90, 12)
+    y = y - y.mean()
+    with pytest.raises(ValueError, match='zero likelihood'):
+        sds_ref.surrogate_slice_sampling(np.zeros(12), x, y, np.array([1., 10., 1.2]), np.array([10., 10., 5.]), literal=False)
+    with pytest.raises(ValueError, match='zero likelihood'):
+        sds_ref.elliptical_slice(np.zeros(12), x, y, np.array([1., 10., 1.2]), nu=np.ones(12))
