@@ -239,3 +239,39 @@ def test_panel_and_gemm_variants_agree(gp):
         gpmc.set_option('panel_impl', 1), gpmc.set_option('gemm_impl', 1), gpmc.set_option('diag_impl', 3)
     for name, v in vals.items():
         assert abs(v - ref) <= 1e-10 * abs(ref), (name, v, ref)
+
+
+def test_large_size_schedule_options_agree(gp):
+    """Options that only take effect with big tiles / look-ahead (N = 4096, look-ahead forced from the start):
+    schedule-only ones (depth-2 look-ahead, enqueue order, panel priority, LDS pad = CU sharing, XCD tile order) must
+    reproduce the default's bits; alternative GEMM kernels (persistent, 8-wave, BK=32 small tiles) the same value to
+    rounding.  All within 1e-10 of SciPy."""
+    n = 4096
+    x, g = _x(n, 2, 5), np.random.RandomState(6).standard_normal(n) * 5.
+    hyp = [1.2, 9.0, 1.1]
+    gpmc = gp['gpmc']
+    base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024}
+    reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 3072, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
+             'panel_prio': 0, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_persistent': 0, 'gemm_8wave': 0,
+             'gemm_small_bk32': 0}
+    variants = (('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('prio', {'panel_prio': 1}),
+                ('share_cu', {'gemm_lds_pad': 9216, 'panel_prio': 1}), ('xcd_map', {'gemm_xcd_map': 1}),
+                ('persistent', {'lookahead': 0, 'gemm_persistent': 1}), ('eight_wave', {'gemm_8wave': 1}),
+                ('bk32', {'gemm_small_bk32': 1}))
+    vals = {}
+    try:
+        for name, opts in variants:
+            for k, v in {**reset, **base, **opts}.items():
+                gpmc.set_option(k, v)
+            plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+            vals[name] = [plan(hyp) for _ in range(2)]
+            plan.close()
+    finally:
+        for k, v in reset.items():
+            gpmc.set_option(k, v)
+    ref = sds_ref.gp_log_marginal(x, g, hyp)
+    for name, v in vals.items():
+        assert v[0] == v[1], name
+        assert abs(v[0] - ref) <= 1e-10 * abs(ref), (name, v[0], ref)
+    for name in ('depth2', 'order1', 'prio', 'share_cu', 'xcd_map'):
+        assert vals[name][0] == vals['default'][0], name
