@@ -173,6 +173,30 @@ def main():
                 raise SystemExit('parity failure vs SciPy at point %d: %r vs %r' % (j, got, v))
 
     extra = {}
+    if rank == 0:
+        # the O(N^2) kernel build alone, against its HBM roofline (bytes = s N^2 written + s N d read;
+        # the lower-only build the plan uses is reported against the same s N^2, and says so)
+        from gpmc import ops
+        np_ = ops.pad(a.n)
+        Wk = torch.empty((np_, np_), dtype=torch.float64, device=dev)
+        Xd = torch.as_tensor(X).to(dev)
+        kp = torch.tensor([pts[0][1] ** 2, 0.0, pts[0][0]], dtype=torch.float64, device=dev)   # [sf2, Sii, ell]
+        kb_bytes = 8.0 * a.n * a.n + 8.0 * a.n * a.d
+        for tag, flags in (('full', ops.KB_FULL), ('lower_only', ops.KB_LOWER | ops.KB_PAD_IDENTITY)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            rc = a.n if tag == 'full' else np_           # the padded build also writes the identity padding
+            for _ in range(3):
+                ops.kbuild('rbf', Xd, kp, Wk, rc, rc, flags)
+            e0.record()
+            for _ in range(20):
+                ops.kbuild('rbf', Xd, kp, Wk, rc, rc, flags)
+            e1.record()
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 20
+            extra['kbuild_' + tag] = {'us': us, 'algorithmic_bytes': kb_bytes, 'GB_per_s': kb_bytes / (us * 1e-6) / 1e9,
+                                      'frac_of_hbm_peak': kb_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        extra['kbuild_lower_only']['note'] = 'writes only the tiles touching the lower triangle; rate quoted against the full s*N^2 bytes'
+        del Wk
     if (a.sds or a.sds_cpu) and rank == 0:
         from gpmc import sds
         ws = sds.SDSWorkspace(X)
