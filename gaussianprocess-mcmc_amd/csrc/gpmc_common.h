@@ -44,7 +44,7 @@ struct Options {
     int f32_nb = 256;         // outer block of the f32 factorisation for np_ >= 4096 (auto mode)
     int gemm_8wave = 0;       // under look-ahead (GEMM at one workgroup per CU) use the 8-wave 128x128 variant
     int la_min_m = 3072;      // under look-ahead: switch to the serial schedule once fewer columns than this remain
-    int panel_prio = 0;       // 1: the fused panel kernel raises its wave priority (s_setprio 3)
+    int panel_prio = 1;       // 1: the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
     int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first
     int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (main = big GEMMs only)
     int gemm_lds_pad_unused = 0;     // extra dynamic LDS bytes requested by the big-tile GEMM (>= 14000 -> 1 workgroup per CU,

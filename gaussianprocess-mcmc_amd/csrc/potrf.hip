@@ -552,13 +552,27 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         GPMC_LAUNCH_CHECK();
         return 0;
     };
-    // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k, the
-    // GEMM held to one workgroup per CU so a panel workgroup always finds a slot) with NB = 256 for np_ >= 6144
-    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused && sizeof(T) == 8) : (g_opt.lookahead != 0);
+    // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k) for
+    // np_ >= 6144, f64 and f32 alike, outer block by remaining columns (la_nb below)
+    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
     if (NB <= 0) NB = la ? 256 : ((sizeof(T) == 4 && np_ >= 4096) ? g_opt.f32_nb : 128);
     if (NB < 128 || NB % 128) NB = 256;
-    g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? 16000 : 0) : g_opt.gemm_lds_pad;
+    // Look-ahead outer block by remaining columns (auto): the panel chain (serial, ~20 us per 64 columns alone) hides
+    // under the update as long as the update is long enough, and a deeper update is a better GEMM (fewer C passes).
+    // Measured (scripts/one_eval.py, ms/eval at N = 16384 / 24576 / 32768): NB 256: 33.8 / 100.5 / 226.6,
+    // 384: 33.4 / 97.5 / 218.5, 512: 34.1 / 96.4 / 215.5.
+    auto la_nb = [&](int rem) {
+        if (g_opt.outer_nb > 0) return NB;
+        if (sizeof(T) == 4) return rem >= 20480 ? 384 : 256;   // f32 (ms/eval at 8192 / 16384 / 24576): serial 5.82 / 22.1 / 60.3,
+                                                                // look-ahead NB 256: 5.32 / 20.6 / 56.7, NB 384: 5.71 / 20.9 / 56.0
+        return rem >= 20480 ? 512 : (rem >= 14336 ? 384 : 256);
+    };
+    // Under look-ahead a padded LDS request holds the big-tile GEMM to one workgroup per CU, so that retiring
+    // workgroups free whole CUs for the panel kernel at a finer grain; that pays below np_ = 8192 only (6144: 3.95 vs
+    // 4.03 ms) -- from 8192 on two GEMM workgroups per CU win (8192: 6.73 vs 6.79, 16384: 33.8 vs 36.2, 32768: 227 vs 253).
+    const int la_pad = (np_ >= 8192) ? 0 : 16000;
+    g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? la_pad : 0) : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
     // serial schedule from column kstart on (the panel at kstart is factored first), outer block nbs
@@ -651,13 +665,13 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         return final_flush();
     }
     // panel 0 on the main stream
+    int nbk = la_nb(np_);
+    if (nbk > np_) nbk = np_;
     {
-        const int nbk = (np_ < NB) ? np_ : NB;
         int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, lpark, s);
         if (rc) return rc;
     }
-    for (int k0 = 0; k0 < np_; k0 += NB) {
-        const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
+    for (int k0 = 0, nb_next = 0; k0 < np_; k0 += nbk, nbk = nb_next) {
         const int k1 = k0 + nbk;
         if (k1 >= np_) break;
         if (np_ - k1 < g_opt.la_min_m) {
@@ -669,7 +683,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (rc) return rc;
             return final_flush();
         }
-        const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;  // next panel width
+        const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);  // next panel width
+        nb_next = nbn;
         // (1) next panel's columns, on s
         int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn, true);
         if (rc) return rc;
