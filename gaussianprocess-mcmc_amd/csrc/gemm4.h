@@ -22,7 +22,7 @@ template <int WGM, int WGN, int RG, int CG, bool EPI, int KCH = 2>
 __global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
-                double diag_add, int g_desync, int xmap) {
+                double diag_add, int g_desync, int xmap, int ktri) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
     constexpr int BKE = 8 * KCH;                           // k elements per stage
@@ -118,8 +118,11 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
             for (int cg = 0; cg < CG; ++cg) acc[rg][cg] = 0.0;
     }
 
-    const double* Ag = A + (size_t)row0 * lda;
-    const double* Bg = B + (size_t)col0 * ldb;
+    // ktri: both operands are upper-trapezoidal (row i is zero left of column i, e.g. L^-T): for a lower tile the
+    // products start at k = row0 (>= col0); skipping the leading zeros makes a full SYRK cost N^3/3 instead of N^3
+    const int kbeg = ktri ? row0 : 0;
+    const double* Ag = A + (size_t)row0 * lda + kbeg;
+    const double* Bg = B + (size_t)col0 * ldb + kbeg;
     d2_t pa[NA], pb[NBI];
     auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -148,7 +151,7 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
         }
     };
 
-    const int nk = K / BKE;
+    const int nk = (K - kbeg) / BKE;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();

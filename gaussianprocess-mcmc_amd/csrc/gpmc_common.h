@@ -110,7 +110,7 @@ template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
            int rows_out, int cols_out, int ldk, int flags, hipStream_t s);
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s);
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0);
 template <typename T>
 int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s);
 template <typename T>
@@ -124,6 +124,8 @@ int unpack_rows(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, hi
 template <typename T>
 int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_, int ldc,
               hipStream_t s);
+template <typename T>
+int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s);
 template <typename T>
 int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s);
 template <typename T>

@@ -194,6 +194,18 @@ int gpmc_potrf_f64(double* W, int mp, int np_, int ldw, int* info_dev, void* scr
 int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream) {
     return potrf<float>(W, mp, np_, ldw, info_dev, scratch, S_(stream));
 }
+int gpmc_potrf_tri_f64(double* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<double>(W, mp, np_, ldw, info_dev, scratch, S_(stream), ntri);
+}
+int gpmc_potrf_tri_f32(float* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<float>(W, mp, np_, ldw, info_dev, scratch, S_(stream), ntri);
+}
+int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int n, int np_, int ldc, gpmc_stream_t stream) {
+    return syrk_tri<double>(P, ldp, diag_add, C, n, np_, ldc, S_(stream));
+}
+int gpmc_syrk_tri_f32(const float* P, int ldp, float diag_add, float* C, int n, int np_, int ldc, gpmc_stream_t stream) {
+    return syrk_tri<float>(P, ldp, diag_add, C, n, np_, ldc, S_(stream));
+}
 int gpmc_logdet_quad_f64(const double* W, int n, int ldw, const double* alpha_dev, const int* info_dev,
                          double* out_dev, gpmc_stream_t stream) {
     return logdet_quad<double>(W, n, ldw, alpha_dev, info_dev, out_dev, S_(stream));

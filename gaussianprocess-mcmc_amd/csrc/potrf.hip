@@ -174,7 +174,7 @@ constexpr int GM_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, const T* Cin, int ldcin,
-               T* C, int ldc, int K, int ntc, int tri, T alpha, int beta, int n_true, T diag_add) {
+               T* C, int ldc, int K, int ntc, int tri, T alpha, int beta, int n_true, T diag_add, int ktri) {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     using frag_t = typename M::frag_t;
@@ -229,8 +229,9 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
             for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = acc_zero<T>();
     }
 
-    const T* Ag = A + (size_t)row0 * lda;
-    const T* Bg = B + (size_t)col0 * ldb;
+    const int kbeg = ktri ? row0 : 0;      // upper-trapezoidal operands: see gemm4.h
+    const T* Ag = A + (size_t)row0 * lda + kbeg;
+    const T* Bg = B + (size_t)col0 * ldb + kbeg;
     frag_t pa[NA], pb[NBI];
     auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -260,7 +261,7 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
         }
     };
 
-    const int nk = K / BK;
+    const int nk = (K - kbeg) / BK;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -308,7 +309,8 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
 
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, int ldcin, T* C, int ldc, int mrows,
-                       int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s) {
+                       int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s,
+                       int ktri = 0) {
     constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
     constexpr int BK = 128 / (int)sizeof(T);
     if (mrows <= 0 || ncols <= 0) return 0;
@@ -325,7 +327,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
-            if (BM == 128 && beta && g_opt.gemm_persistent && g_lds_pad_now == 0 && nblk >= 64) {
+            if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && g_lds_pad_now == 0 && nblk >= 64) {
                 // persistent pipelined kernel: one 512-thread workgroup per CU walks the tile list, next C tile
                 // prefetched under the current K loop
                 auto kp = gemm4p_nt_kernel<EPI>;
@@ -351,7 +353,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attr8_done = true;
                 }
                 hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)g_lds_pad_now, s, A, lda, B, ldb, Cin, ldcin,
-                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0);
+                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0, ktri);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -365,7 +367,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attrs_done = true;
                 }
                 hipLaunchKernelGGL(ks, dim3(nblk), dim3(256), smems, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                                   alpha, beta, n_true, diag_add, 0, 0);
+                                   alpha, beta, n_true, diag_add, 0, 0, ktri);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -385,7 +387,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 xmap = mt;
             }
             hipLaunchKernelGGL(k4, dim3(nblk4), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap);
+                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap, ktri);
             GPMC_LAUNCH_CHECK();
             return 0;
         }
@@ -398,7 +400,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri, alpha,
-                       beta, n_true, diag_add);
+                       beta, n_true, diag_add, ktri);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
@@ -535,7 +537,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
 }
 
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s) {
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri) {
     GPMC_ARG(W != nullptr, 1);
     GPMC_ARG(np_ > 0 && np_ % GPMC_PAD == 0, 3);
     GPMC_ARG(mp >= np_ && mp % GPMC_PAD == 0, 2);
@@ -543,6 +545,12 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(info_dev != nullptr, 5);
     GPMC_ARG(scratch != nullptr, 6);
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
+    GPMC_ARG(ntri >= 0 && ntri % GPMC_PAD == 0 && ntri <= mp - np_, 8);
+    // The last ntri riding rows are upper-trapezoidal on entry (riding row mp - ntri + i is zero left of column i, e.g.
+    // a scaled identity, which leaves s L^-T behind).  Row i then stays zero in every column < i, so while the panel
+    // ending at column kend is factored or applied only the first kend of those rows can hold anything: the launches
+    // stop at row mp_at(kend) and the riding work drops from N^3 to N^3/3.
+    auto mp_at = [&](int kend) { return ntri > 0 ? mp - ntri + (kend < ntri ? kend : ntri) : mp; };
     T* dinv = reinterpret_cast<T*>(scratch);
     double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
     const bool fused = (g_opt.panel_impl >= 1);
@@ -579,11 +587,11 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     auto serial_from = [&](int kstart, int nbs) -> int {
         for (int k0 = kstart; k0 < np_; k0 += nbs) {
             const int nbk = (np_ - k0 < nbs) ? np_ - k0 : nbs;
-            int rc = factor_panel<T>(W, ldw, k0, nbk, mp, info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
+            int rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
             if (rc) return rc;
             const int k1 = k0 + nbk;
             if (k1 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
                 if (rc) return rc;
             }
         }
@@ -620,7 +628,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             GPMC_HIP(hipEventRecord(ef, s));
             GPMC_HIP(hipStreamWaitEvent(ps, ef, 0));
             const int nbk = (np_ < NB) ? np_ : NB;
-            int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, lpark, ps);
+            int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, ps);
             if (rc) return rc;
             pe_prev = next_ev();
             GPMC_HIP(hipEventRecord(pe_prev, ps));
@@ -636,7 +644,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 // tail: join, bring the whole remaining matrix up to panel k, continue serially with NB = 128
                 GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
                 g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
-                int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+                int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
                 if (rc) return rc;
                 rc = serial_from(k1, 128);
                 if (rc) return rc;
@@ -646,16 +654,16 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             const int k2 = k1 + nbn;
             // panel stream: U_{k+1}, P_{k+1}
             if (ge_prev) GPMC_HIP(hipStreamWaitEvent(ps, ge_prev, 0));
-            int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, ps, k1, k2, true);
+            int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, ps, k1, k2, true);
             if (rc) return rc;
-            rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
+            rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k2), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
             if (rc) return rc;
             hipEvent_t pe_next = next_ev();
             GPMC_HIP(hipEventRecord(pe_next, ps));
             // main stream: G_k
             GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
             if (k2 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k2, np_);
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_);
                 if (rc) return rc;
                 ge_prev = next_ev();
                 GPMC_HIP(hipEventRecord(ge_prev, s));
@@ -668,7 +676,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     int nbk = la_nb(np_);
     if (nbk > np_) nbk = np_;
     {
-        int rc = factor_panel<T>(W, ldw, 0, nbk, mp, info_dev, dinv, lpark, s);
+        int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, s);
         if (rc) return rc;
     }
     for (int k0 = 0, nb_next = 0; k0 < np_; k0 += nbk, nbk = nb_next) {
@@ -677,7 +685,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (np_ - k1 < g_opt.la_min_m) {
             // tail: the GEMM no longer hides the (contention-stretched) panel chain -> serial, NB = 128, 2 WGs/CU
             g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
-            int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, np_);
+            int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
             if (rc) return rc;
             rc = serial_from(k1, 128);
             if (rc) return rc;
@@ -686,7 +694,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);  // next panel width
         nb_next = nbn;
         // (1) next panel's columns, on s
-        int rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1, k1 + nbn, true);
+        int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, k1 + nbn, true);
         if (rc) return rc;
         hipEvent_t e1 = next_ev();
         GPMC_HIP(hipEventRecord(e1, s));
@@ -695,18 +703,18 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // la_order = 1 issues (3) before (2), so the main-stream chain (1) -> (3) -> (1') stays on one queue and
         // the crossings move to the panel chain, which has slack.
         if (g_opt.la_order == 1 && k1 + nbn < np_) {
-            rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1 + nbn, np_);
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_);
             if (rc) return rc;
         }
         // (2) factor next panel on ps
         GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
-        rc = factor_panel<T>(W, ldw, k1, nbn, mp, info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
+        rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k1 + nbn), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
         if (rc) return rc;
         hipEvent_t e2 = next_ev();
         GPMC_HIP(hipEventRecord(e2, ps));
         // (3) the rest of the trailing matrix, on s, concurrently with (2)
         if (g_opt.la_order != 1 && k1 + nbn < np_) {
-            rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k1 + nbn, np_);
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_);
             if (rc) return rc;
         }
         GPMC_HIP(hipStreamWaitEvent(s, e2, 0));
@@ -724,6 +732,18 @@ int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C
     if (np_ > g_opt.small_tile_m)
         return launch_gemm<T, 2, 2, 4, 4, true>(P, ldp, P, ldp, D, ldd, C, ldc, np_, np_, kp, 1, (T)-1, 1, n, diag_add, s);
     return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, D, ldd, C, ldc, np_, np_, kp, 1, (T)-1, 1, n, diag_add, s);
+}
+
+// C = diag_add I - P P^T for an upper-trapezoidal P (row i zero left of column i; n x np_ inside an np_ x np_ padded
+// square whose padding becomes the identity): the products of a lower tile start at its first row -> N^3/3 flops.
+template <typename T>
+int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s) {
+    GPMC_ARG(P && C, 1);
+    GPMC_ARG(n > 0 && n <= np_ && np_ % GPMC_PAD == 0, 5);
+    GPMC_ARG(ldc >= np_ && ldp >= np_, 7);
+    if (np_ > g_opt.small_tile_m)
+        return launch_gemm<T, 2, 2, 4, 4, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1);
+    return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1);
 }
 
 // rows (nrows x np_, ldr) <- rows L^-T with L the lower triangle of W (f64): 64-column blocks, MFMA TRSM on the
@@ -788,8 +808,10 @@ int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStrea
     return 0;
 }
 
-template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t);
-template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t);
+template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int);
+template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int);
+template int syrk_tri<double>(const double*, int, double, double*, int, int, int, hipStream_t);
+template int syrk_tri<float>(const float*, int, float, float*, int, int, int, hipStream_t);
 template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);
 template int syrk_diff<float>(const float*, int, const float*, int, int, float, float*, int, int, int, hipStream_t);
 

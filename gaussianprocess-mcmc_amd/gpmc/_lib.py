@@ -49,6 +49,10 @@ def _sig(lib):
         'gpmc_pack_rows_f64': ([P, I, I, I, P, I, I, I, P], I), 'gpmc_pack_rows_f32': ([P, I, I, I, P, I, I, I, P], I),
         'gpmc_unpack_lower_f64': ([P, I, I, P, I, I, P], I), 'gpmc_unpack_lower_f32': ([P, I, I, P, I, I, P], I),
         'gpmc_unpack_rows_f64': ([P, I, I, P, I, I, I, P], I), 'gpmc_unpack_rows_f32': ([P, I, I, P, I, I, I, P], I),
+        'gpmc_potrf_tri_f64': ([P, I, I, I, I, P, P, P], I),
+        'gpmc_potrf_tri_f32': ([P, I, I, I, I, P, P, P], I),
+        'gpmc_syrk_tri_f64': ([P, I, c_double, P, I, I, I, P], I),
+        'gpmc_syrk_tri_f32': ([P, I, c_float, P, I, I, I, P], I),
         'gpmc_syrk_diff_f64': ([P, I, P, I, I, c_double, P, I, I, I, P], I),
         'gpmc_syrk_diff_f32': ([P, I, P, I, I, c_float, P, I, I, I, P], I),
         'gpmc_symv_lower_f64': ([P, I, I, P, P, P], I), 'gpmc_symv_lower_f32': ([P, I, I, P, P, P], I),

@@ -62,6 +62,12 @@ def potrf(W, mp, np_, info, scratch):
                                 stream_ptr()), 'gpmc_potrf')
 
 
+def potrf_tri(W, mp, np_, ntri, info, scratch):
+    """gpmc_potrf_tri: the last ``ntri`` riding rows are upper-trapezoidal on entry (e.g. s*I -> s*L^-T)"""
+    check(_fn('potrf_tri', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), ntri, info.data_ptr(), scratch.data_ptr(),
+                                    stream_ptr()), 'gpmc_potrf_tri')
+
+
 def logdet_quad(W, n, alpha, info, out):
     check(_fn('logdet_quad', W.dtype)(W.data_ptr(), n, W.stride(0), alpha.data_ptr(),
                                       0 if info is None else info.data_ptr(), out.data_ptr(), stream_ptr()),
@@ -95,6 +101,13 @@ def unpack_rows(W, np_, nrhs, n, out=None):
     check(_fn('unpack_rows', W.dtype)(W.data_ptr(), np_, W.stride(0), out.data_ptr(), nrhs, n, out.stride(0),
                                       stream_ptr()), 'gpmc_unpack_rows')
     return out
+
+
+def syrk_tri(P, C, n, np_, diag_add=0.0):
+    """C = diag_add*I - P P^T for an upper-trapezoidal P (np_ x np_ rows of gpmc_potrf_tri)"""
+    check(_fn('syrk_tri', C.dtype)(P.data_ptr(), P.stride(0), float(diag_add), C.data_ptr(), n, np_, C.stride(0),
+                                   stream_ptr()), 'gpmc_syrk_tri')
+    return C
 
 
 def syrk_diff(D, P, kp, C, n, np_, diag_add=0.0):

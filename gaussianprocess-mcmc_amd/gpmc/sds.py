@@ -2,18 +2,23 @@
 
 Mirror of ``aux_var_model`` (kcMCMC/sliceSample.py:165-207) plus the two expressions that consume it
 (``ita``, sliceSample.py:108; ``prop_f``, :140; ``curG``/``propG``, :122,147), with every dense step a
-libgpmc kernel and nothing but scalars and N-vectors crossing to the host:
+libgpmc kernel and nothing but scalars and N-vectors crossing to the host.
 
-    workspace A, (2 np_ + 128) x np_ :  rows [0, np_)       K + S   (lower; S_ii fused by the K build)
-                                        rows [np_, 2 np_)   K       (full; becomes V^T = K L^-T)
-                                        row  2 np_          g       (becomes alpha^T = (L^-1 g)^T)
-    gpmc_potrf(A)                    -> L, V^T, alpha in one factorisation            (a3, a4, a11's TRSV)
-    workspace R, (np_ + 128) x np_   :  K (lower) -> gpmc_syrk_diff -> R = K - V^T V   (a5)
-    m = gpmc_symv_lower(R, g / S)                                                       (a6)
-    R += 1e-11 I ; row np_ = f - m ; gpmc_potrf(R) -> C = chol(R), eta = C^-1 (f - m)   (a7, a9)
-    f' = gpmc_trmv_lower(C, eta) + m                                                    (a10)
+Default form ``'inv'`` (4 N^3 / 3 flops per proposal).  With S = s I (the kernel diagonal is constant, so S_ii is one
+scalar) and A = K + S = L L^T:   R = K - V^T V = K - K A^-1 K  ==  S - S A^-1 S  =  s I - (s L^-T)(s L^-T)^T.
 
-The reference spends ~11.3 N^3 flops here (dense S, LU solves, two inverses); this path 8 N^3 / 3.
+    workspace A, (2 np_ + 128) x np_ :  rows [0, np_)            K + S   (lower; S_ii fused by the K build)
+                                        row  np_                 g       (becomes alpha^T = (L^-1 g)^T)
+                                        rows [np_+128, 2np_+128) s I     (becomes P = s L^-T, upper-trapezoidal)
+    gpmc_potrf_tri(A, ntri = np_)    -> L, alpha, P in one factorisation; the trapezoidal rows cost N^3/3   (a3, a4, a11)
+    workspace R, (np_ + 128) x np_   :  gpmc_syrk_tri -> R + 1e-11 I = (s + 1e-11) I - P P^T, N^3/3           (a5, a7's shift)
+    m = gpmc_symv_lower(R, g / s)                                                                             (a6)
+    row np_ = f - m ; gpmc_potrf(R) -> C = chol(R + 1e-11 I), eta = C^-1 (f - m)                              (a7, a9)
+    f' = gpmc_trmv_lower(C, eta) + m                                                                          (a10)
+
+Form ``'syrk'`` is the first implementation (8 N^3 / 3): K itself rides on the factorisation (V^T = K L^-T, N^3) and
+R = K - V^T V is a full SYRK (N^3); kept for cross-checks.  Both follow the reference's seeded chains decision for
+decision (tests/test_gpu_sds.py); the reference itself spends ~11.3 N^3 flops here (dense S, LU solves, two inverses).
 """
 import numpy as np
 import torch
@@ -24,10 +29,13 @@ R_JITTER = 1e-11          # sliceSample.py:205
 
 
 class SDSWorkspace(object):
-    def __init__(self, x, kernel='rbf', dtype=torch.float64):
+    def __init__(self, x, kernel='rbf', dtype=torch.float64, form='inv'):
         ops.require_gpu()
+        if form not in ('inv', 'syrk'):
+            raise ValueError("form must be 'inv' or 'syrk'")
         self.kernel = kernel
         self.dtype = dtype
+        self.form = form
         self.X = ops.to_dev(x, dtype)
         if self.X.dim() == 1:
             self.X = self.X.reshape(-1, 1)
@@ -37,6 +45,9 @@ class SDSWorkspace(object):
         self.np_ = np_ = ops.pad(n)
         self.mpA = 2 * np_ + ops.PAD
         self.mpR = np_ + ops.PAD
+        # 'inv': g block right below the matrix, the trapezoidal rows LAST (gpmc_potrf_tri); 'syrk': K rows, then g
+        self.g_row = np_ if form == 'inv' else 2 * np_
+        self.rows0 = np_ + ops.PAD if form == 'inv' else np_
         self.WA = torch.zeros((self.mpA, np_), dtype=dtype, device=dev)
         self.WR = torch.zeros((self.mpR, np_), dtype=dtype, device=dev)
         self.infoA = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -60,26 +71,45 @@ class SDSWorkspace(object):
         self.kp0.copy_(torch.as_tensor(kp0, dtype=self.dtype))
 
     def _factor_A(self, g, jitter):
-        """K + S (+ jitter) with K and g riding: L, V^T = K L^-T, alpha = L^-1 g, then the log-marginal reduction"""
+        """K + S (+ jitter) with g and either s I ('inv') or K ('syrk') riding: L, alpha = L^-1 g and P = s L^-T or
+        V^T = K L^-T, then the log-marginal reduction"""
         n, np_ = self.n, self.np_
         if jitter:
             self.kpS[1] = self.Sii + jitter
+        self._sA = self.Sii + jitter                              # what was added to the diagonal of K
         ops.kbuild(self.kernel, self.X, self.kpS, self.WA, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
-        ops.kbuild(self.kernel, self.X, self.kp0, self.WA[np_:2 * np_], np_, np_, ops.KB_FULL)
-        self.WA[2 * np_, :n].copy_(g)
-        ops.potrf(self.WA, self.mpA, np_, self.infoA, self.scratch)
-        ops.logdet_quad(self.WA, n, self.WA[2 * np_], self.infoA, self.out)
+        rows = self.WA[self.rows0:self.rows0 + np_]
+        if self.form == 'inv':
+            rows.zero_()                                          # last proposal's P; O(N^2) memset
+            torch.diagonal(rows).fill_(self._sA)
+        else:
+            ops.kbuild(self.kernel, self.X, self.kp0, rows, np_, np_, ops.KB_FULL)
+        self.WA[self.g_row, :n].copy_(g)
+        if self.form == 'inv':
+            ops.potrf_tri(self.WA, self.mpA, np_, np_, self.infoA, self.scratch)
+        else:
+            ops.potrf(self.WA, self.mpA, np_, self.infoA, self.scratch)
+        ops.logdet_quad(self.WA, n, self.WA[self.g_row], self.infoA, self.out)
 
     def _factor_R(self, f, g, need_eta, jitter):
-        """R = K - V^T V, m = R S^-1 g, C = chol(R + (1e-11 + jitter) I), eta = C^-1 (f - m)"""
+        """R = K - V^T V (= S - S A^-1 S), m = R S^-1 g, C = chol(R + (1e-11 + jitter) I), eta = C^-1 (f - m)"""
         n, np_ = self.n, self.np_
-        ops.kbuild(self.kernel, self.X, self.kp0, self.WR, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
-        ops.syrk_diff(self.WR, self.WA[np_:2 * np_], np_, self.WR, n, np_, 0.0)
+        rows = self.WA[self.rows0:self.rows0 + np_]
         torch.div(g, self.Sii, out=self.gs)                      # O(N) vector scaling (S^-1 g)
-        ops.symv_lower(self.WR, n, self.gs, self.m)
-        if jitter:
-            self._Rdiag_mean = float(self.WR.diagonal()[:n].mean())
-        self.WR.diagonal()[:n].add_(R_JITTER + jitter)
+        if self.form == 'inv':
+            shift = R_JITTER + jitter
+            ops.syrk_tri(rows, self.WR, n, np_, self._sA + shift)           # R + shift I in one pass
+            ops.symv_lower(self.WR, n, self.gs, self.m)
+            self.m.add_(self.gs, alpha=-shift)                    # m = R S^-1 g exactly as before the shift
+            if jitter:
+                self._Rdiag_mean = float(self.WR.diagonal()[:n].mean()) - shift
+        else:
+            ops.kbuild(self.kernel, self.X, self.kp0, self.WR, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+            ops.syrk_diff(self.WR, rows, np_, self.WR, n, np_, 0.0)
+            ops.symv_lower(self.WR, n, self.gs, self.m)
+            if jitter:
+                self._Rdiag_mean = float(self.WR.diagonal()[:n].mean())
+            self.WR.diagonal()[:n].add_(R_JITTER + jitter)
         if need_eta:
             torch.sub(f, self.m, out=self.WR[np_, :n])
         else:
@@ -90,7 +120,7 @@ class SDSWorkspace(object):
         """Factor everything for hyper-parameters ``hyp`` given latent f and auxiliary g (device vectors).
 
         Returns G = log N(g; 0, K + S); afterwards self.m, the lower triangle of self.WR (= chol_R_theta),
-        self.eta (if need_eta) and self.WA (L, V^T, alpha) are valid.  A failed factorisation follows the
+        self.eta (if need_eta) and self.WA (L, alpha, and P = s L^-T or V^T) are valid.  A failed factorisation follows the
         jitchol schedule the reference pins (pyGPs 1.3.4): mean(diag) * 1e-9 added, x10 per retry, ``maxtries``
         retries, then np.linalg.LinAlgError propagates to the caller exactly as in the reference."""
         self._set_hyp(hyp)

@@ -77,6 +77,15 @@ int gpmc_kbuild_f32(int kernel, const float* X, int n, int d, int ldx, const flo
  */
 int gpmc_potrf_f64(double* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream);
 int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scratch, gpmc_stream_t stream);
+/* As gpmc_potrf, for riding rows whose LAST ntri rows (ntri a multiple of GPMC_PAD, <= mp - np_) are
+ * upper-trapezoidal on entry: riding row mp - ntri + i is zero left of column i.  A scaled identity s I there
+ * returns s L^-T, i.e. the explicit inverse factor, for N^3/3 flops instead of the N^3 of a dense right-hand side:
+ * those rows stay zero left of their diagonal, so every launch stops at the last row that can hold anything.
+ * This is how the SDS block gets R = S - S (K+S)^-1 S (== K - V^T V, sliceSample.py:197-198) -- see gpmc_syrk_tri. */
+int gpmc_potrf_tri_f64(double* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch,
+                       gpmc_stream_t stream);
+int gpmc_potrf_tri_f32(float* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch,
+                       gpmc_stream_t stream);
 
 /* ---- a11: log-marginal reduction --------------------------------------------------------------
  * Replaces the curG/propG expression of sliceSample.py:122,147 given the factor and alpha = L^-1 g:
@@ -122,6 +131,17 @@ int gpmc_syrk_diff_f64(const double* D, int ldd, const double* P, int kp, int ld
                        int n, int np_, int ldc, gpmc_stream_t stream);
 int gpmc_syrk_diff_f32(const float* D, int ldd, const float* P, int kp, int ldp, float diag_add, float* C,
                        int n, int np_, int ldc, gpmc_stream_t stream);
+
+/* ---- a4+a5 in inverse form:  C = diag_add I - P P^T  for an upper-trapezoidal P ---------------------------
+ * P (np_ x np_, ldp; row i zero left of column i) = S^(1/2)-scaled inverse factor left behind by gpmc_potrf_tri
+ * with riding rows s I:  P P^T = s^2 (K+S)^-1, so diag_add = s (+ 1e-11) gives R_theta (+ 1e-11 I) of
+ * sliceSample.py:198,205 through the identity K - K (K+S)^-1 K = S - S (K+S)^-1 S.  The k loop of a lower tile starts
+ * at the tile's first row: N^3/3 flops.  Identity on the padding (i >= n).
+ */
+int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int n, int np_, int ldc,
+                      gpmc_stream_t stream);
+int gpmc_syrk_tri_f32(const float* P, int ldp, float diag_add, float* C, int n, int np_, int ldc,
+                      gpmc_stream_t stream);
 
 /* ---- a6/a10: symmetric / triangular matrix-vector products on workspace matrices ----------------
  * symv_lower:  y = A_sym x   using only the lower triangle of A (n x n inside W)   (m = R (g/S), :204)

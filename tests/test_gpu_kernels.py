@@ -275,3 +275,76 @@ def test_large_size_schedule_options_agree(gp):
         assert abs(v[0] - ref) <= 1e-10 * abs(ref), (name, v[0], ref)
     for name in ('depth2', 'order1', 'prio', 'share_cu', 'xcd_map'):
         assert vals[name][0] == vals['default'][0], name
+
+
+# ----------------------------------------------------------------------- inverse-form SDS kernels
+@pytest.mark.parametrize('n,dtype', [(64, 'f64'), (200, 'f64'), (455, 'f64'), (1500, 'f64'), (4200, 'f64'),
+                                     (6500, 'f64'), (1000, 'f32')])
+def test_potrf_tri_returns_scaled_inverse_factor(gp, n, dtype):
+    """gpmc_potrf_tri: riding rows = [g block ; s I]; the trapezoidal rows must come back as s L^-T (zero left of the
+    diagonal, bit for bit), the g row as L^-1 g, and L itself identical to the plain factorisation.  6500 runs the
+    look-ahead schedule, 4200 the big tiles."""
+    ops = gp['ops']
+    td = torch.float64 if dtype == 'f64' else torch.float32
+    A = _spd(n, n + 1, cond=1e3)
+    s = 1.7
+    np_ = ops.pad(n)
+    mp = np_ + ops.PAD + np_
+    W = torch.zeros((mp, np_), dtype=td, device='cuda')
+    At = torch.as_tensor(A).to(device='cuda', dtype=td)
+    ops.pack_lower(At, W, np_, 0.0)
+    g = np.random.RandomState(n).standard_normal(n)
+    W[np_, :n] = torch.as_tensor(g).to(W)
+    torch.diagonal(W[np_ + ops.PAD:]).fill_(s)
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.potrf_tri(W, mp, np_, np_, info, ops.potrf_scratch(np_, W.device))
+    assert int(info.item()) == 0
+    Lref = scipy.linalg.cholesky(A, lower=True)
+    L = ops.unpack_lower(W, np_, n).cpu().numpy().astype(np.float64)
+    P = W[np_ + ops.PAD:np_ + ops.PAD + n, :n].cpu().numpy().astype(np.float64)
+    alpha = W[np_, :n].cpu().numpy().astype(np.float64)
+    Pref = s * scipy.linalg.solve_triangular(Lref, np.eye(n), lower=True).T
+    tol = 1e-11 if dtype == 'f64' else 2e-4
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=tol * np.abs(Lref).max())
+    np.testing.assert_allclose(P, Pref, rtol=0, atol=tol * np.abs(Pref).max())
+    np.testing.assert_allclose(alpha, scipy.linalg.solve_triangular(Lref, g, lower=True), rtol=0,
+                               atol=tol * max(1.0, np.abs(alpha).max()))
+    assert np.all(np.tril(P, -1) == 0)                       # never touched
+    # the plain factorisation of the same matrix gives the same L, bit for bit (the riding rows do not feed back)
+    W2 = torch.zeros((np_ + ops.PAD, np_), dtype=td, device='cuda')
+    ops.pack_lower(At, W2, np_, 0.0)
+    ops.potrf(W2, np_ + ops.PAD, np_, info, ops.potrf_scratch(np_, W.device))
+    assert torch.equal(ops.unpack_lower(W2, np_, n), ops.unpack_lower(W, np_, n))
+
+
+@pytest.mark.parametrize('n', [64, 200, 1000, 3300])
+def test_syrk_tri_matches_dense(gp, n):
+    """C = d I - P P^T for an upper-trapezoidal P: lower triangle vs NumPy, identity on the padding"""
+    ops = gp['ops']
+    np_ = ops.pad(n)
+    rng = np.random.RandomState(n)
+    P = np.triu(rng.standard_normal((n, n)))
+    Pw = torch.zeros((np_, np_), dtype=torch.float64, device='cuda')
+    Pw[:n, :n] = torch.as_tensor(P).cuda()
+    torch.diagonal(Pw)[n:].fill_(3.0)                       # what the padding of the factorisation leaves there
+    C = torch.full((np_ + ops.PAD, np_), float('nan'), dtype=torch.float64, device='cuda')
+    ops.syrk_tri(Pw, C, n, np_, 0.25)
+    Cn = C[:np_].cpu().numpy()
+    ref = 0.25 * np.eye(n) - P @ P.T
+    low = np.tril_indices(n)
+    np.testing.assert_allclose(Cn[:n, :n][low], ref[low], rtol=0, atol=1e-12 * np.abs(ref).max())
+    if np_ > n:
+        pad = Cn[n:, :]
+        assert np.all(np.diag(Cn)[n:] == 1.0)
+        assert np.all(np.tril(pad[:, :n]) == 0) or np.all(pad[:, :n][np.tril_indices_from(pad[:, :n])] == 0)
+
+
+def test_potrf_tri_argument_checks(gp):
+    ops = gp['ops']
+    W = torch.zeros((384, 128), dtype=torch.float64, device='cuda')
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    scr = ops.potrf_scratch(128, W.device)
+    with pytest.raises(gp['gpmc'].GpmcError):
+        ops.potrf_tri(W, 384, 128, 100, info, scr)           # not a multiple of the padding unit
+    with pytest.raises(gp['gpmc'].GpmcError):
+        ops.potrf_tri(W, 384, 128, 384, info, scr)           # more trapezoidal rows than riding rows

@@ -55,11 +55,13 @@ def test_symv_trmv_syrk_units(gp):
     assert np.all(np.diag(full)[n:] == 1.0) and np.all(np.tril(full, -1)[n:, :] == 0.0)
 
 
+@pytest.mark.parametrize('form', ['inv', 'syrk'])
 @pytest.mark.parametrize('n', [8, 64, 200])
-def test_aux_var_model_device_vs_reference_fixture(golden_dir, gp, n):
-    """aux_var_model outputs of the reference (sliceSample.py:165-207) on the fixture's inputs."""
+def test_aux_var_model_device_vs_reference_fixture(golden_dir, gp, n, form):
+    """aux_var_model outputs of the reference (sliceSample.py:165-207) on the fixture's inputs, for the default
+    inverse form (R = S - S (K+S)^-1 S, 4N^3/3 flops) and the first implementation (R = K - V^T V, 8N^3/3)."""
     z = _load(golden_dir, 'aux_n%d.npz' % n)
-    ws = gp['sds'].SDSWorkspace(z['x'])
+    ws = gp['sds'].SDSWorkspace(z['x'], form=form)
     f, g = torch.as_tensor(z['f']).cuda(), torch.as_tensor(z['g_in']).cuda()
     G = ws.aux_var_model(f, z['hyp'], g, need_eta=True)
     assert abs(G - float(z['curG'])) <= 1e-8 * abs(float(z['curG']))          # the north_star bar
@@ -202,6 +204,30 @@ def test_full_size_sds_proposal_properties(gp):
     assert float((fp - f).abs().max()) < 1e-5
     ref = sds_ref.gp_log_marginal(X, g0, [1.0, 10.0, 1.2])
     assert abs(G - ref) <= 1e-8 * abs(ref)
+
+
+def test_sds_forms_agree_at_size(gp):
+    """N = 4096 (big tiles, trapezoidal riding rows, triangular SYRK): the two algebraic forms of the SDS block give the
+    same L bit for bit (the riding rows do not feed back), the same log-marginal, m to 1e-9 and R + 1e-11 I to 1e-8 in
+    C C^T; each reproduces f through eta."""
+    n = 4096
+    X, g0 = _bench_like(n, 2)
+    f = torch.as_tensor(np.random.RandomState(2).standard_normal(n)).cuda()
+    g = torch.as_tensor(g0).cuda()
+    out = {}
+    for form in ('inv', 'syrk'):
+        ws = gp['sds'].SDSWorkspace(X, form=form)
+        G = ws.aux_var_model(f, [1.3, 9.0, 1.1], g, need_eta=True)
+        C = ws.chol_R()
+        fp = ws.propose_f(ws.eta.clone())
+        assert float((fp - f).abs().max()) < 1e-5
+        out[form] = (G, ws.L_KS().clone(), ws.m.clone(), (C @ C.t()))
+        del ws
+    assert out['inv'][0] == out['syrk'][0]
+    assert torch.equal(out['inv'][1], out['syrk'][1])
+    mi, ms = out['inv'][2], out['syrk'][2]
+    assert float((mi - ms).abs().max()) <= 1e-9 * float(ms.abs().max())
+    assert float((out['inv'][3] - out['syrk'][3]).abs().max()) <= 1e-8
 
 
 def test_config5_shape_f32_vs_f64(gp):
