@@ -212,7 +212,7 @@ def main():
             ws.propose_f(eta).cpu()
         torch.cuda.synchronize()
         extra['sds_proposals_per_s'] = reps / (time.perf_counter() - t1)
-        extra['sds_flops_per_proposal'] = 8.0 * a.n ** 3 / 3.0
+        extra['sds_flops_per_proposal'] = 4.0 * a.n ** 3 / 3.0     # inverse form (gpmc/sds.py)
         del ws
         if a.sds_cpu:
             # the reference's literal op sequence (sliceSample.py:136-147,165-207) through the oracle restatement
