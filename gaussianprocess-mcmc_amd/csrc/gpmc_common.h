@@ -130,6 +130,8 @@ template <typename T>
 int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s);
 template <typename T>
 int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStream_t s);
+template <typename T>
+int trmv_upper(const T* W, int n, int ldw, const T* x, const T* y0, double alpha, T* y, hipStream_t s);
 
 // look-ahead resources (second stream + events), created lazily per process
 struct Aux {

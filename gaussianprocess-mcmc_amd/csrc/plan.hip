@@ -238,6 +238,14 @@ int gpmc_logdet_quad_f32(const float* W, int n, int ldw, const float* alpha_dev,
     int gpmc_trmv_lower_##SFX(const T* W, int n, int ldw, const T* x, const T* y0, T* y, gpmc_stream_t st) {      \
         return trmv_lower<T>(W, n, ldw, x, y0, y, S_(st));                                                        \
     }
+int gpmc_trmv_upper_f64(const double* W, int n, int ldw, const double* x, const double* y0, double alpha, double* y,
+                        gpmc_stream_t st) {
+    return trmv_upper<double>(W, n, ldw, x, y0, alpha, y, S_(st));
+}
+int gpmc_trmv_upper_f32(const float* W, int n, int ldw, const float* x, const float* y0, double alpha, float* y,
+                        gpmc_stream_t st) {
+    return trmv_upper<float>(W, n, ldw, x, y0, alpha, y, S_(st));
+}
 PACK_API(f64, double)
 PACK_API(f32, float)
 

@@ -171,6 +171,33 @@ trmv_lower_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__
     if (lane == 0) y[i] = (T)(s + (y0 ? (double)y0[i] : 0.0));
 }
 
+// trmv_upper: y = y0 + alpha * (U x) for an upper-trapezoidal U stored by rows (row i holds columns >= i; whatever
+// lies left of the diagonal is not read), one wave per row, fixed summation order.
+template <typename T>
+__global__ void __launch_bounds__(256)
+trmv_upper_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ x, const T* __restrict__ y0,
+                  double alpha, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= n) return;
+    double s = 0.0;
+    const int j0 = i & ~63;                                  // aligned start: 512-byte segments for f64
+    for (int j = j0 + lane; j < n; j += 64)
+        if (j >= i) s += (double)W[(size_t)i * ldw + j] * (double)x[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[i] = (T)((y0 ? (double)y0[i] : 0.0) + alpha * s);
+}
+
+template <typename T>
+int trmv_upper(const T* W, int n, int ldw, const T* x, const T* y0, double alpha, T* y, hipStream_t s) {
+    GPMC_ARG(W && n > 0 && ldw >= n, 1);
+    GPMC_ARG(x && y && x != y, 4);
+    hipLaunchKernelGGL((trmv_upper_kernel<T>), dim3((n + 3) / 4), dim3(256), 0, s, W, n, ldw, x, y0, alpha, y);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s) {
     GPMC_ARG(W && n > 0 && ldw >= n, 1);
@@ -195,7 +222,8 @@ int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStr
     template int unpack_lower<T>(const T*, int, int, T*, int, int, hipStream_t);                             \
     template int unpack_rows<T>(const T*, int, int, T*, int, int, int, hipStream_t);                         \
     template int symv_lower<T>(const T*, int, int, const T*, T*, hipStream_t);                               \
-    template int trmv_lower<T>(const T*, int, int, const T*, const T*, T*, hipStream_t);
+    template int trmv_lower<T>(const T*, int, int, const T*, const T*, T*, hipStream_t);                     \
+    template int trmv_upper<T>(const T*, int, int, const T*, const T*, double, T*, hipStream_t);
 INST(double)
 INST(float)
 

@@ -57,6 +57,8 @@ def _sig(lib):
         'gpmc_syrk_diff_f32': ([P, I, P, I, I, c_float, P, I, I, I, P], I),
         'gpmc_symv_lower_f64': ([P, I, I, P, P, P], I), 'gpmc_symv_lower_f32': ([P, I, I, P, P, P], I),
         'gpmc_trmv_lower_f64': ([P, I, I, P, P, P, P], I), 'gpmc_trmv_lower_f32': ([P, I, I, P, P, P, P], I),
+        'gpmc_trmv_upper_f64': ([P, I, I, P, P, c_double, P, P], I),
+        'gpmc_trmv_upper_f32': ([P, I, I, P, P, c_double, P, P], I),
         'gpmc_plan_workspace_bytes': ([I, I, I], c_size_t),
         'gpmc_plan_create': ([ctypes.POINTER(c_void_p), I, I, I, I, P, c_size_t, P], I),
         'gpmc_plan_set_data': ([P, P, I, P], I),

@@ -128,6 +128,14 @@ def trmv_lower(W, n, x, y0, y):
     return y
 
 
+def trmv_upper(W, n, x, y0, alpha, y):
+    """y = y0 + alpha * (U x), U = the upper-trapezoidal rows held in W (row i: columns >= i)"""
+    check(_fn('trmv_upper', W.dtype)(W.data_ptr(), n, W.stride(0), x.data_ptr(),
+                                     0 if y0 is None else y0.data_ptr(), float(alpha), y.data_ptr(), stream_ptr()),
+          'gpmc_trmv_upper')
+    return y
+
+
 def trsm_rows(W, np_, R, nrows):
     check(_lib.lib().gpmc_trsm_rows_f64(W.data_ptr(), np_, W.stride(0), R.data_ptr(), nrows, R.stride(0), stream_ptr()),
           'gpmc_trsm_rows_f64')

@@ -153,6 +153,13 @@ int gpmc_trmv_lower_f64(const double* W, int n, int ldw, const double* x, const 
 int gpmc_symv_lower_f32(const float* W, int n, int ldw, const float* x, float* y, gpmc_stream_t stream);
 int gpmc_trmv_lower_f32(const float* W, int n, int ldw, const float* x, const float* y0, float* y,
                         gpmc_stream_t stream);
+/* y = y0 + alpha * (U x) for an upper-trapezoidal U stored by rows (row i: columns >= i; nothing left of the diagonal
+ * is read); y0 may be NULL.  With U = P = s L^-T (gpmc_potrf_tri), x = alpha = L^-1 g (the riding row), y0 = g and
+ * alpha = -1 this is m_theta_g = R S^-1 g = g - P (L^-1 g) of sliceSample.py:204 without forming R first. */
+int gpmc_trmv_upper_f64(const double* W, int n, int ldw, const double* x, const double* y0, double alpha, double* y,
+                        gpmc_stream_t stream);
+int gpmc_trmv_upper_f32(const float* W, int n, int ldw, const float* x, const float* y0, double alpha, float* y,
+                        gpmc_stream_t stream);
 
 /* ---- a16: triangular solves with an existing factor (tools.solve_chol, sliceSample.py:258; also :120,145,202) ----
  * trsm_rows: R (nrows x np_, ldr; nrows multiple of 64) <- R L^-T, i.e. row r becomes (L^-1 b_r)^T, with L the lower

@@ -348,3 +348,20 @@ def test_potrf_tri_argument_checks(gp):
         ops.potrf_tri(W, 384, 128, 100, info, scr)           # not a multiple of the padding unit
     with pytest.raises(gp['gpmc'].GpmcError):
         ops.potrf_tri(W, 384, 128, 384, info, scr)           # more trapezoidal rows than riding rows
+
+
+@pytest.mark.parametrize('n', [1, 63, 200, 1000])
+def test_trmv_upper(gp, n):
+    """y = y0 + alpha U x with U the upper triangle of the stored rows; the strict lower part must not be read"""
+    ops = gp['ops']
+    rng = np.random.RandomState(n)
+    M = rng.standard_normal((n, n))
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    Wd = torch.as_tensor(M).cuda()
+    Wd[np.tril_indices(n, -1)] = float('nan')
+    y = torch.empty(n, dtype=torch.float64, device='cuda')
+    ops.trmv_upper(Wd, n, torch.as_tensor(x).cuda(), torch.as_tensor(y0).cuda(), -1.5, y)
+    ref = y0 - 1.5 * (np.triu(M) @ x)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
+    ops.trmv_upper(Wd, n, torch.as_tensor(x).cuda(), None, 1.0, y)
+    np.testing.assert_allclose(y.cpu().numpy(), np.triu(M) @ x, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
