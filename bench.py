@@ -7,7 +7,7 @@ BASELINE.json's metric is quoted on: RBF kernel, N = 8192, d = 2, fp64, syntheti
 the host.  Evaluations are issued back to back on one stream with distinct hyper-parameters cycled from 16
 points drawn from the sampler's bracket; nothing is cached between steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--sds] [--sds-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--sds] [--sds-cpu] [--chain K]
 
 --sds adds to "extra" the rate of FULL surrogate-data-slice proposals (K, chol(K+S),
 V = L^-1 K, R = K - V^T V, m, chol R, f', log-marginal) on the same inputs; --sds-cpu (implies --sds) also times ONE
@@ -99,6 +99,8 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--sds', action='store_true', help='also time full SDS proposals (reported in "extra")')
     ap.add_argument('--sds-cpu', action='store_true', help='also time one literal reference-sequence proposal on the host')
+    ap.add_argument('--chain', type=int, default=0, metavar='K',
+                    help='also run K iterations of the real sampler (surrogate_slice_sampling) on these inputs: iterations/s')
     a = ap.parse_args()
 
     import torch
@@ -225,6 +227,21 @@ def main():
             _ = np.dot(C_, eta.cpu().numpy()) + m_
             _ = sds_ref.log_marginal_literal(g, K_S, L_)
             extra['sds_cpu_literal_s_per_proposal'] = time.perf_counter() - t1
+
+    if a.chain > 0 and rank == 0:
+        # chain-level cross-check: the real sampler from the framework's initial point; targets are a
+        # bounded series in the reference's data range, one aux_var_model + several full SDS proposals per iteration
+        from gpmc import framework
+        yb = np.clip(50. + g, 1., 99.)
+        np.random.seed(124)
+        framework.run_chain(X, yb, 1, framework.FRAMEWORK_HYP0)                      # warm-up (workspaces)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, hh, ntries = framework.run_chain(X, yb, a.chain, framework.FRAMEWORK_HYP0)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        extra['chain'] = {'iterations': a.chain, 'iterations_per_s': a.chain / el,
+                          'proposals_per_iteration': float(np.mean(ntries)), 'last_hyp': [float(v) for v in hh[:, -1]]}
 
     if rank == 0:
         value = world * a.steps / tmax

@@ -365,3 +365,28 @@ def test_trmv_upper(gp, n):
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
     ops.trmv_upper(Wd, n, torch.as_tensor(x).cuda(), None, 1.0, y)
     np.testing.assert_allclose(y.cpu().numpy(), np.triu(M) @ x, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
+
+
+def test_two_live_plans_interleaved(gp):
+    """Two plans alive in one process (different sizes, one of them on the look-ahead schedule) share the library's
+    auxiliary panel stream and event ring; interleaved asynchronous evaluations must still return each plan's own
+    values, bit for bit equal to what the plan computes alone."""
+    core = gp['core']
+    xa, ga = _x(6400, 2, 21), np.random.RandomState(22).standard_normal(6400) * 5.
+    xb, gb = _x(1500, 2, 23), np.random.RandomState(24).standard_normal(1500) * 5.
+    hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [0.7, 12.0, 1.5]]
+    pa, pb = core.LogMarginalPlan(xa, ga, 'rbf'), core.LogMarginalPlan(xb, gb, 'rbf')
+    alone_a = [pa(h) for h in hyps]
+    alone_b = [pb(h) for h in hyps]
+    for rep in range(2):
+        for i, h in enumerate(hyps):
+            pa.eval_async(h, i)
+            pb.eval_async(h, i)
+        got_a = [pa.result(i)[0] for i in range(3)]
+        got_b = [pb.result(i)[0] for i in range(3)]
+        assert got_a == alone_a and got_b == alone_b
+    ref = sds_ref.gp_log_marginal(xb, gb, hyps[1])
+    assert abs(alone_b[1] - ref) <= 1e-10 * abs(ref)
+    pa.close()
+    assert pb(hyps[0]) == alone_b[0]                           # closing one plan leaves the other intact
+    pb.close()
