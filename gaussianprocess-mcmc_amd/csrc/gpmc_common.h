@@ -33,28 +33,29 @@ inline int fail(int code, const char* fmt, ...) {
 
 // ---------------------------------------------------------------- options
 struct Options {
-    int outer_nb = 0;     // outer block of the right-looking Cholesky (multiple of 128); 0 = auto (128, or 256 with look-ahead)
-    int lookahead = -1;   // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: only for
-                          // np_ >= 6144, where the GEMM is long enough to hide the (contention-stretched) panel chain
-    int use_graph = 1;    // capture the plan's launch sequence into a hipGraph
+    // ---- schedule (defaults = the auto rules of potrf())
+    int outer_nb = 0;         // outer block of the right-looking Cholesky (multiple of 128); 0 = auto: 128 serial (f32: f32_nb
+                              // from np_ 4096), under look-ahead 256 / 384 / 512 by remaining columns
+    int lookahead = -1;       // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: np_ >= 6144
+    int la_min_m = 3072;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
+    int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (measured slower)
+    int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first (measured slower)
+    int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
+    int use_graph = 1;        // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
-    int gemm_lds_pad = -1;    // -1 = auto (16000 under look-ahead, else 0)
+    int f32_nb = 256;         // outer block of the serial f32 factorisation for np_ >= 4096
+    int gemm_lds_pad = -1;    // extra dynamic LDS bytes requested by the big-tile f64 GEMM under look-ahead; -1 = auto: 16000
+                              // (one workgroup per CU) below np_ = 8192, 0 from there on
+    // ---- alternative kernels kept for the measurements that led to the defaults
+    int gemm_impl = 1;        // 1: v_mfma_f64_4x4x4 slab GEMM (f64), 0: v_mfma_*_16x16x4 GEMM
     int gemm_persistent = 0;  // big-tile f64 trailing update: persistent 8-wave kernel with C-tile prefetch (gemm4p.h)
     int gemm_small_bk32 = 0;  // small-tile (64x64) f64 GEMM: 32 k per LDS stage instead of 16
-    int f32_nb = 256;         // outer block of the f32 factorisation for np_ >= 4096 (auto mode)
-    int gemm_8wave = 0;       // under look-ahead (GEMM at one workgroup per CU) use the 8-wave 128x128 variant
-    int la_min_m = 3072;      // under look-ahead: switch to the serial schedule once fewer columns than this remain
-    int panel_prio = 1;       // 1: the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
-    int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first
-    int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (main = big GEMMs only)
-    int gemm_lds_pad_unused = 0;     // extra dynamic LDS bytes requested by the big-tile GEMM (>= 14000 -> 1 workgroup per CU,
-                              // leaving half of every CU to the look-ahead panel kernel)
-    int gemm_xcd_map = 0;     // 1: XCD-aware 8x8 super-block tile order in the 4x4x4 GEMM
-    int gemm_desync = 0;      // 1: alternate dispatch waves fold C in after the K loop (breaks the lock-step)
-    int gemm_impl = 1;        // 1: v_mfma_f64_4x4x4 slab GEMM (f64), 0: v_mfma_*_16x16x4 GEMM
-    int panel_impl = 1;       // 1: fused kernel (4 waves, default); 2: fused kernel with in-block look-ahead (5 waves; measured
-                              // +-0.5 %: the workers become the long pole); 0: three kernels
-    int diag_impl = 3;        // 0: LDS column loop, 1: single wave, 2: register-blocked VALU, 3: micro-panel + MFMA 4x4x4
+    int gemm_8wave = 0;       // with a padded LDS request (one GEMM workgroup per CU) use the 8-wave 128x128 variant
+    int gemm_xcd_map = 0;     // XCD-aware 8x8 super-block tile order in the 4x4x4 GEMM (halves L2 misses, not faster)
+    int gemm_desync = 0;      // 1: alternate dispatch waves fold C in after the K loop; >= 2: phase-shift experiments
+    int panel_impl = 1;       // 1: fused kernel (4 waves); 2: fused kernel with in-block look-ahead (5 waves, +-0.5 %);
+                              // 0: three kernels (diag factor, strip TRSM, GEMM)
+    int diag_impl = 3;        // with panel_impl 0: 0 LDS column loop, 1 single wave, 2 register-blocked VALU, 3 micro-panel + MFMA
 };
 extern Options g_opt;
 
