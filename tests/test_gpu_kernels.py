@@ -390,3 +390,22 @@ def test_two_live_plans_interleaved(gp):
     pa.close()
     assert pb(hyps[0]) == alone_b[0]                           # closing one plan leaves the other intact
     pb.close()
+
+
+@pytest.mark.parametrize('n,bad', [(6500, 0), (6500, 3000), (6500, 6400), (6500, 6499), (4200, 4100)])
+def test_first_bad_pivot_is_reported_under_lookahead(gp, n, bad):
+    """LAPACK-style info (1-based index of the first non-positive pivot) through the look-ahead schedule (6500), where
+    panels are factored on a second stream, and the serial big-tile schedule (4200); a later, second bad pivot must
+    not overwrite the first."""
+    ops = gp['ops']
+    B = np.random.RandomState(n + 7).standard_normal((n, 32))
+    A = B @ B.T + 10. * np.eye(n)                          # SPD, cheap to form
+    A[bad, bad] = -abs(A[bad, bad])
+    if bad + 50 < n:
+        A[bad + 50, bad + 50] = -1.0
+    np_ = ops.pad(n)
+    W = torch.zeros((np_ + ops.PAD, np_), dtype=torch.float64, device='cuda')
+    ops.pack_lower(torch.as_tensor(A).cuda(), W, np_, 0.0)
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.potrf(W, np_ + ops.PAD, np_, info, ops.potrf_scratch(np_, W.device))
+    assert int(info.item()) == bad + 1
