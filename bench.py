@@ -167,7 +167,7 @@ def main():
 
     # parity of the timed path against the oracle on this rank's first points (checker, outside the timed region)
     cpu = None
-    if rank == 0 and not a.no_cpu:
+    if rank == 0 and world == 1 and not a.no_cpu:          # the host baseline is timed at N = 1 only
         cpu, vals = cpu_baseline(X, g, pts)
         for j, v in enumerate(vals[:2]):
             got = plan(pts[j])
