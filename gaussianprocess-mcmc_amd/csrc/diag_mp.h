@@ -39,10 +39,23 @@ __device__ inline double mp_rsqrt(double d) {
 #if MP_RSQ_ITERS >= 2
     g = __builtin_fma(g, r, g);
     r = __builtin_fma(-h, g, 0.5);
-    h = __builtin_fma(h, r, h);
-#endif
+    const double h2 = h + h;                 // off the dependent chain: 2h(1 + r) in one fma
+    return __builtin_fma(h2, r, h2);
+#else
     return h + h;
+#endif
 }
+
+// MP_FASTPIVOT = 1 (experiment, compiled out): form pivot k+1 ahead of the vector update, d' = A - B^2 / d with
+// A = p[k+1](row k+1), B = p[k](row k+1) read BEFORE 1/sqrt(d) is known (both are final one column earlier); the
+// multipliers are then the uniform B rs and no v_readlane sits between two pivots.  Measured: the factor wave's
+// micro-step goes from ~2260 to 2104 ticks, the block's factor phase stays at ~24K and N = 2048 / 4096 / 8192 do not
+// move (0.92 / 2.24 / 6.83 ms).  The ISA explains it: ~260 instructions per micro-step at ~8 cycles each -- FP64 VALU
+// instructions issue every ~8 cycles at one wave per SIMD even when independent -- so this phase is bound by
+// instruction issue, and the variant trades a shorter chain for more FP64 instructions (20 vs 13.5 per column).
+#ifndef MP_FASTPIVOT
+#define MP_FASTPIVOT 0
+#endif
 
 // Slabs of wave w: D[m][h], m = 0..3 (slab row g = w + 4m), h = 0..m.
 // One micro-step, T8 compile-time.  All 256 threads call; two barriers inside.
@@ -75,6 +88,33 @@ __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], d
         int bad = 0;                                         // wave-uniform: 1-based first non-positive pivot
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[k] = Praw[row][k];
+#if MP_FASTPIVOT
+        double d = mp_readlane(p[0], 8 * T8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pr = 8 * T8 + k;                       // pivot row == pivot column
+            // uniform pre-reads from the unscaled column k and from column k+1 (both final w.r.t. columns < k)
+            double B[8];
+#pragma unroll
+            for (int k2 = k + 1; k2 < 8; ++k2) B[k2] = mp_readlane(p[k], 8 * T8 + k2);
+            const double A = (k < 7) ? mp_readlane(p[(k < 7) ? k + 1 : k], pr + 1) : 0.0;
+            bad = (bad == 0 && !(d > 0.0)) ? (pr + 1) : bad;
+            const double rs = mp_rsqrt(d);
+            rsv[k] = rs;
+            if (k < 7) {
+                const double b2 = B[(k < 7) ? k + 1 : k] * B[(k < 7) ? k + 1 : k];
+                d = __builtin_fma(-b2, rs * rs, A);          // next pivot: the only thing the next rsq waits for
+            }
+            const double lk = p[k] * rs;                     // row pr: d * rs = sqrt(d) to ~1 ulp; rows above: junk, zeroed below
+            p[k] = lk;
+#pragma unroll
+            for (int k2 = k + 1; k2 < 8; ++k2) {
+                const double mlt = B[k2] * rs;               // L[8T8+k2][8T8+k], uniform
+                p[k2] = __builtin_fma(-lk, mlt, p[k2]);
+                asm volatile("" : "+v"(p[k2]));
+            }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int pr = 8 * T8 + k;                       // pivot row == pivot column
@@ -94,6 +134,7 @@ __device__ inline void mp_micro_step(double (&D)[4][4], double (*Lout)[MP_LD], d
                 asm volatile("" : "+v"(p[k2]));
             }
         }
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) Lout[row][8 * T8 + k] = (row < 8 * T8 + k) ? 0.0 : p[k];
         if (lane < 8) {
