@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Accuracy of the device Cholesky / log-marginal vs SciPy at a few sizes (development)."""
 import os, sys
-import numpy as np, scipy.linalg, torch
+import numpy as np, scipy.linalg, torch  # noqa: F401
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'gaussianprocess-mcmc_amd')); sys.path.insert(0, R)
 from gpmc import core, tools

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does the device chain first take a different decision than the oracle (lean SciPy) chain? (development)"""
 import os, sys
-import numpy as np, torch
+import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'gaussianprocess-mcmc_amd')); sys.path.insert(0, R)
 from gpmc import framework, sliceSample

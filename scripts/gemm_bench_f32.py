@@ -3,7 +3,6 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gaussianprocess-mcmc_amd'))
-import gpmc
 from gpmc import ops
 np_ = 16384
 for kp in (128, 256, 512, 1024, 4096):

@@ -6,7 +6,7 @@
 Run one mode per process: a heap corruption in the runtime aborts the interpreter.
 """
 import ctypes, os, sys
-import numpy as np, torch
+import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gaussianprocess-mcmc_amd'))
 import gpmc
 from gpmc import core, _lib

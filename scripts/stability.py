@@ -3,7 +3,6 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gaussianprocess-mcmc_amd'))
-import gpmc
 from gpmc import core
 n = 8192
 rng = np.random.RandomState(124)

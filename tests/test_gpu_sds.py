@@ -4,7 +4,6 @@ import os
 
 import numpy as np
 import pytest
-import scipy.linalg
 
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
