@@ -95,11 +95,14 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     // coincide and leave the MFMA pipe idle ~1/3 of a K=128 tile.  Every other dispatch wave of 256 workgroups
     // therefore accumulates from zero and folds C in AFTER the K loop: one workgroup's memory phase then sits
     // under its neighbour's MFMA phase.  (Which workgroups share a CU is a guess that only affects speed.)
-    const bool c_last = beta && (g_desync == 1) && ((blockIdx.x >> 8) & 1);
-    if (g_desync >= 2) {   // experiment: phase-shift part of the grid by ~g_desync/10 of a K=128 tile lifetime
-        const int sel = (g_desync & 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+    const bool c_last = beta && ((g_desync & 0xff) == 1) && ((blockIdx.x >> 8) & 1);
+    if ((g_desync & 0xffef) >= 2) {   // experiment: delay half of the first 512 workgroups at kernel start
+        // value = 256 * bit + 2 * reps (+ 16 = streaming C, see below): blocks whose index has `bit` set (default 8,
+        // i.e. the second slot of every CU if the dispatcher deals one block per CU per pass) sleep reps x 3.4 us
+        const int bit = (g_desync >> 8) ? (g_desync >> 8) : 8;
+        const int sel = (g_desync & 1) ? (blockIdx.x & 1) : ((blockIdx.x >> bit) & 1);
         if (sel && blockIdx.x < 512) {
-            const int reps = g_desync >> 1;
+            const int reps = (g_desync & 0xe) >> 1;
             for (int r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
         }
     }

@@ -37,6 +37,8 @@ struct Options {
     int outer_nb = 0;         // outer block of the right-looking Cholesky (multiple of 128); 0 = auto: 128 serial (f32: f32_nb
                               // from np_ 4096), under look-ahead 256 / 384 / 512 by remaining columns
     int lookahead = -1;       // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: np_ >= 6144
+    int la_min_np = 6144;     // auto look-ahead from this padded size on
+    int la_nb128_m = 0;       // under look-ahead: outer block 128 once fewer columns than this remain (0 = never)
     int la_min_m = 3072;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
     int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (measured slower)
     int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first (measured slower)

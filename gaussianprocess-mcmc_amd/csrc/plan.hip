@@ -121,6 +121,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
     else if (!strcmp(name, "gemm_lds_pad")) g_opt.gemm_lds_pad = value;
     else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
+    else if (!strcmp(name, "la_min_np")) g_opt.la_min_np = value;
+    else if (!strcmp(name, "la_nb128_m")) g_opt.la_nb128_m = value;
     else if (!strcmp(name, "panel_prio")) g_opt.panel_prio = value ? 1 : 0;
     else if (!strcmp(name, "la_order")) g_opt.la_order = value ? 1 : 0;
     else if (!strcmp(name, "la_depth")) g_opt.la_depth = (value == 2) ? 2 : 1;
@@ -144,6 +146,8 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_xcd_map")) return g_opt.gemm_xcd_map;
     if (!strcmp(name, "gemm_lds_pad")) return g_opt.gemm_lds_pad;
     if (!strcmp(name, "la_min_m")) return g_opt.la_min_m;
+    if (!strcmp(name, "la_min_np")) return g_opt.la_min_np;
+    if (!strcmp(name, "la_nb128_m")) return g_opt.la_nb128_m;
     if (!strcmp(name, "la_depth")) return g_opt.la_depth;
     if (!strcmp(name, "la_order")) return g_opt.la_order;
     if (!strcmp(name, "panel_prio")) return g_opt.panel_prio;

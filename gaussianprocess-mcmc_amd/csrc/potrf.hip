@@ -562,7 +562,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     };
     // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k) for
     // np_ >= 6144, f64 and f32 alike, outer block by remaining columns (la_nb below)
-    const bool la = (g_opt.lookahead < 0) ? (np_ >= 6144 && fused) : (g_opt.lookahead != 0);
+    const bool la = (g_opt.lookahead < 0) ? (np_ >= g_opt.la_min_np && fused) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
     if (NB <= 0) NB = la ? 256 : ((sizeof(T) == 4 && np_ >= 4096) ? g_opt.f32_nb : 128);
     if (NB < 128 || NB % 128) NB = 256;
@@ -572,6 +572,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // 384: 33.4 / 97.5 / 218.5, 512: 34.1 / 96.4 / 215.5.
     auto la_nb = [&](int rem) {
         if (g_opt.outer_nb > 0) return NB;
+        if (rem < g_opt.la_nb128_m) return 128;
         if (sizeof(T) == 4) return rem >= 20480 ? 384 : 256;   // f32 (ms/eval at 8192 / 16384 / 24576): serial 5.82 / 22.1 / 60.3,
                                                                 // look-ahead NB 256: 5.32 / 20.6 / 56.7, NB 384: 5.71 / 20.9 / 56.0
         return rem >= 20480 ? 512 : (rem >= 14336 ? 384 : 256);
