@@ -119,41 +119,43 @@ int unpack_rows(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, hi
 }
 
 // ----------------------------------------------------------------------- matrix-vector products
-// symv_lower: y = A x from the lower triangle only.  Workgroup b owns rows/columns I = [64b, 64b+64):
-//   row part    sum_{j <= i} A[i][j] x[j]   (rows of I, coalesced along j)
-//   column part sum_{j >  I} A[j][i] x[j]   (rows below I, 64-wide coalesced segments)
-// Fixed summation order; every lower element is read twice in total (HBM-bound, 2 * s * N^2/2 bytes).
+// symv_lower: y = A x from the lower triangle only, in two launches with a fixed summation order:
+//   1. row part     y[i]  = sum_{j <= i} A[i][j] x[j]   -- trmv_lower_kernel, one wave per row
+//   2. column part  y[i] += sum_{j >  i} A[j][i] x[j]   -- symv_cols_kernel below: workgroup b owns columns
+//      [64b, 64b+64) (so every y[i] has exactly one writer), 16 waves stride the rows below, lane = column (512-byte
+//      coalesced row segments), 8 independent partial sums per lane.
+// Every lower element is read twice in total (HBM-bound, 2 * s * N^2/2 bytes).  The first version did both parts in
+// one 256-thread workgroup per 64 rows -- 512 waves on the whole chip, 0.65 TB/s (0.83 ms at N = 8192).
 template <typename T>
-__global__ void __launch_bounds__(256)
-symv_lower_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ x, T* __restrict__ y) {
-    __shared__ double part[4][64];
-    __shared__ double rowsum[64];
+__global__ void __launch_bounds__(1024)
+symv_cols_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ x, T* __restrict__ y) {
+    __shared__ double part[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i0 = blockIdx.x * 64;
-    // row part
-    for (int rr = wv; rr < 64; rr += 4) {
-        const int i = i0 + rr;
-        double s = 0.0;
-        if (i < n)
-            for (int j = lane; j <= i; j += 64) s += (double)W[(size_t)i * ldw + j] * (double)x[j];
+    const int i = i0 + lane;
+    double s = 0.0;
+    if (i < n) {
+        double p[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) rowsum[rr] = s;
+        for (int u = 0; u < 8; ++u) p[u] = 0.0;
+        int j = i0 + 64 + wv;
+        for (; j + 16 * 7 < n; j += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] += (double)W[(size_t)(j + 16 * u) * ldw + i] * (double)x[j + 16 * u];
+        }
+        for (; j < n; j += 16) p[0] += (double)W[(size_t)j * ldw + i] * (double)x[j];
+        // rows of the diagonal block below the diagonal: j in (i, i0 + 64)
+        for (int jj = i + 1 + wv; jj < min(i0 + 64, n); jj += 16) p[1] += (double)W[(size_t)jj * ldw + i] * (double)x[jj];
+        s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     }
-    // column part
-    {
-        const int i = i0 + lane;
-        double s = 0.0;
-        if (i < n)
-            for (int j = i0 + 64 + wv; j < n; j += 4) s += (double)W[(size_t)j * ldw + i] * (double)x[j];
-        // rows of the diagonal block below the diagonal: j in (i, i0+64)
-        if (i < n)
-            for (int j = i + 1 + wv; j < min(i0 + 64, n); j += 4) s += (double)W[(size_t)j * ldw + i] * (double)x[j];
-        part[wv][lane] = s;
-    }
+    part[wv][lane] = s;
     __syncthreads();
-    if (tid < 64 && i0 + tid < n)
-        y[i0 + tid] = (T)(rowsum[tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])));
+    if (tid < 64 && i0 + tid < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][tid];
+        y[i0 + tid] = (T)((double)y[i0 + tid] + t);
+    }
 }
 
 // trmv_lower: y = L x + y0 (y0 may be null), one wave per row.
@@ -202,7 +204,9 @@ template <typename T>
 int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s) {
     GPMC_ARG(W && n > 0 && ldw >= n, 1);
     GPMC_ARG(x && y && x != y, 4);
-    hipLaunchKernelGGL((symv_lower_kernel<T>), dim3((n + 63) / 64), dim3(256), 0, s, W, n, ldw, x, y);
+    hipLaunchKernelGGL((trmv_lower_kernel<T>), dim3((n + 3) / 4), dim3(256), 0, s, W, n, ldw, x, (const T*)nullptr, y);
+    GPMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((symv_cols_kernel<T>), dim3((n + 63) / 64), dim3(1024), 0, s, W, n, ldw, x, y);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
