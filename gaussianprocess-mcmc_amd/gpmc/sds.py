@@ -191,10 +191,12 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     """Protocol-compatible ``aux_var_model(f, K, sn, g=None)`` -> (g, K+S, m_theta_g, chol_R_theta, L)
     for a dense K handed in by the caller (ndarray or device tensor); everything returned is a device
     tensor.  Slower than SDSWorkspace (K is packed instead of built in place) -- it exists so code written
-    against the reference's function keeps working."""
-    from . import tools
+    against the reference's function keeps working.  Same inverse form as SDSWorkspace, here with the general
+    (vector) S of sliceSample.py:183-190: riding rows diag(S) come back as P = S L^-T, R = diag(S) - P P^T,
+    m = g - P (L^-1 g)."""
     Kd = ops.to_dev(K)
     n = Kd.shape[0]
+    dev, dt = Kd.device, Kd.dtype
     f = ops.to_dev(f).reshape(-1)
     Kii = torch.diagonal(Kd)
     kinv = 1. / Kii
@@ -204,22 +206,29 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     else:
         g = ops.to_dev(g).reshape(-1)
     np_ = ops.pad(n)
-    ws = tools.FactorWorkspace(n, n, Kd.dtype, Kd.device)
     KS = Kd + torch.diag(Sii)
-    ops.pack_lower(KS, ws.W, np_, 0.0)
-    ops.pack_rows(Kd, ws.W, ws.mp, np_, n)
-    ws.factor()
-    if ws.info_host() != 0:
-        raise np.linalg.LinAlgError('K + S not positive definite (pivot %d)' % ws.info_host())
-    L = ops.unpack_lower(ws.W, np_, n)
-    wr = tools.FactorWorkspace(n, 0, Kd.dtype, Kd.device)
-    ops.pack_lower(Kd, wr.W, np_, 0.0)
-    ops.syrk_diff(wr.W, ws.W[np_:], ws.mp - np_, wr.W, n, np_, 0.0)
-    m = torch.empty(n, dtype=Kd.dtype, device=Kd.device)
-    ops.symv_lower(wr.W, n, g / Sii, m)
-    wr.W.diagonal()[:n].add_(R_JITTER)
-    wr.factor()
-    if wr.info_host() != 0:
-        raise np.linalg.LinAlgError('R not positive definite (pivot %d)' % wr.info_host())
-    C = ops.unpack_lower(wr.W, np_, n)
+    # workspace: [K + S ; g block ; diag(S) rows]  (layout of SDSWorkspace form 'inv')
+    mpA = 2 * np_ + ops.PAD
+    WA = torch.zeros((mpA, np_), dtype=dt, device=dev)
+    ops.pack_lower(KS, WA, np_, 0.0)
+    WA[np_, :n].copy_(g)
+    rows = WA[np_ + ops.PAD:]
+    torch.diagonal(rows)[:n].copy_(Sii)
+    if np_ > n:
+        torch.diagonal(rows)[n:].fill_(1.0)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = ops.potrf_scratch(np_, dev)
+    ops.potrf_tri(WA, mpA, np_, np_, info, scratch)
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError('K + S not positive definite (pivot %d)' % int(info.item()))
+    L = ops.unpack_lower(WA, np_, n)
+    WR = torch.zeros((np_ + ops.PAD, np_), dtype=dt, device=dev)
+    ops.syrk_tri(rows, WR, n, np_, 0.0)                      # -P P^T (identity on the padding)
+    WR.diagonal()[:n].add_(Sii + R_JITTER)                   # R + 1e-11 I = diag(S) - P P^T + 1e-11 I
+    m = torch.empty(n, dtype=dt, device=dev)
+    ops.trmv_upper(rows, n, WA[np_], g, -1.0, m)
+    ops.potrf(WR, np_ + ops.PAD, np_, info, scratch)
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError('R not positive definite (pivot %d)' % int(info.item()))
+    C = ops.unpack_lower(WR, np_, n)
     return g, KS, m, C, L

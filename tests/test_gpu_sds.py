@@ -88,6 +88,25 @@ def test_aux_var_model_protocol_function(golden_dir, gp):
     np.testing.assert_allclose(Cn @ Cn.T, z['C'] @ z['C'].T, rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize('n', [200, 1100])
+def test_aux_var_model_protocol_function_general_K(gp, n):
+    """a dense K with a NON-constant diagonal, so S of sliceSample.py:183-190 goes through the per-element expression
+    (it equals sn^2 up to rounding whatever K_ii is); against the oracle's literal restatement (dense S, solve, inv)"""
+    from oracle.kcgp_ref import covK as ocov
+    rng = np.random.RandomState(n)
+    x = rng.uniform(0, 10, (n, 2))
+    d = rng.uniform(0.7, 1.3, n)
+    K = ocov.RBF(np.log(1.5), np.log(3.0)).getCovMatrix(x=x, mode='train') * np.outer(d, d)
+    f, g_in, sn = rng.standard_normal(n), rng.standard_normal(n) * 3., 0.9
+    g0, KS0, m0, C0, L0 = sds_ref.aux_var_model_literal(f, K, sn, g=g_in)
+    g, K_S, m, C, L = gp['sliceSample'].aux_var_model(f, K, sn, g=g_in)
+    np.testing.assert_allclose(K_S.cpu().numpy(), KS0, rtol=1e-14)
+    np.testing.assert_allclose(L.cpu().numpy(), L0, rtol=0, atol=1e-11 * np.abs(L0).max())
+    np.testing.assert_allclose(m.cpu().numpy(), m0, rtol=0, atol=1e-8 * np.abs(m0).max())
+    Cn = C.cpu().numpy()
+    np.testing.assert_allclose(Cn @ Cn.T, C0 @ C0.T, rtol=0, atol=1e-8)
+
+
 def test_log_gamma_matches_reference_fixture(golden_dir, gp):
     z = _load(golden_dir, 'log_gamma.npz')
     for i, row in enumerate(z['x']):
