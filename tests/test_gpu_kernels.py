@@ -409,3 +409,18 @@ def test_first_bad_pivot_is_reported_under_lookahead(gp, n, bad):
     info = torch.zeros(1, dtype=torch.int32, device='cuda')
     ops.potrf(W, np_ + ops.PAD, np_, info, ops.potrf_scratch(np_, W.device))
     assert int(info.item()) == bad + 1
+
+
+def test_plan_input_dimension_limits(gp):
+    """the plan stages up to 62 ARD length-scales (PLAN_MAXD): d = 62 works and matches the oracle, d = 63 is refused
+    with an error, not truncated"""
+    n = 300
+    rng = np.random.RandomState(62)
+    x = rng.uniform(0, 3, (n, 62))
+    g = rng.standard_normal(n)
+    hyp = np.concatenate([rng.uniform(2.0, 6.0, 62), [1.5, 0.8]])
+    got = gp['core'].log_marginal(x, g, hyp, kernel='matern52ard')
+    ref = sds_ref.gp_log_marginal(x, g, hyp, kernel='matern52ard')
+    assert abs(got - ref) <= 1e-8 * abs(ref)
+    with pytest.raises(gp['gpmc'].GpmcError):
+        gp['core'].LogMarginalPlan(rng.uniform(0, 3, (n, 63)), g, 'matern52ard')
