@@ -42,6 +42,9 @@ struct Options {
     int la_min_m = 3072;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
     int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (measured slower)
     int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first (measured slower)
+    int panel_pair = 1;       // first 128 columns of an outer panel in one launch (panel_pair.h): 0 never, 1 under look-ahead
+                              // (6144: 3.96 -> 3.83 ms, 8192: 6.69 -> 6.50, 12288: -1.3 %, f32 16384: -2.3 %), 2 everywhere
+                              // (serial phases: +1.7 % at 2048 / 4096)
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
     int use_graph = 1;        // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles

@@ -42,6 +42,28 @@ __device__ inline void st2<float>(float* p, d2_t v) {
     *reinterpret_cast<f2_t*>(p) = o;
 }
 
+// flush duties shared by both panel kernels: copy what the previous panel launch parked back into W -- up to two
+// diagonal factors (duties 0, 1) and one L21 block (duty 2: rows c+64.., columns c..).  Duty k is done by workgroup
+// min(k, gridDim.x - 1): the last launches of a workspace without riding rows have fewer than three workgroups.
+template <typename TS>
+__device__ inline void panel_flush_duties(TS* __restrict__ W, int ld, const double* __restrict__ lpark,
+                                          const double* __restrict__ lpark21, int prev_c0, int prev2_c0, int prev21_c0,
+                                          int tid) {
+    const int b = blockIdx.x, last = (int)gridDim.x - 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (b != (k < last ? k : last)) continue;
+        const int pc = (k == 0) ? prev_c0 : (k == 1 ? prev2_c0 : prev21_c0);
+        if (pc < 0) continue;
+        const double* src = ((k == 2) ? lpark21 : lpark) + (size_t)(pc / 64) * 4096;
+        const size_t r0 = (size_t)pc + (k == 2 ? 64 : 0), q0 = (size_t)pc;
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            st2<TS>(&W[(r0 + row) * ld + q0 + c2], *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]));
+        }
+    }
+}
+
 struct PanelShared {
     // Ld: chunk of the diagonal strip's rows [row][k] (phase 1); the SAME storage then holds the diagonal
     // block's factor Lout (phases 2-3).  78,856 B in all.  LDS budget of the look-ahead: a CU has 163,840 B; the
@@ -70,7 +92,8 @@ static_assert(sizeof(PanelShared) <= 62 * 1280, "PanelShared must stay within 62
 template <bool DBG, typename TS>
 __global__ void __launch_bounds__(256)
 panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__ info,
-                   double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg, int hi_prio) {
+                   double* __restrict__ lpark, int prev_c0, unsigned long long* __restrict__ dbg, int hi_prio,
+                   const double* __restrict__ lpark21, int prev2_c0, int prev21_c0) {
     // Beside the trailing GEMM (look-ahead) every SIMD also holds a GEMM wave issuing MFMAs back to back; this
     // kernel is a latency chain, so its waves ask for issue priority.
     if (hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -83,13 +106,9 @@ panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__
     const size_t R0 = (size_t)c0 + 64 * (size_t)blockIdx.x;
     PANEL_STAMP(0);
 
-    if (is_diag && prev_c0 >= 0) {   // flush the previous block's factor (nobody reads that block in this launch)
-        const double* src = lpark + (size_t)(prev_c0 / 64) * 4096;
-        for (int e = tid; e < 64 * 32; e += 256) {
-            const int row = e >> 5, c2 = (e & 31) * 2;
-            st2<TS>(&W[((size_t)prev_c0 + row) * ld + prev_c0 + c2], *reinterpret_cast<const d2_t*>(&src[row * 64 + c2]));
-        }
-    }
+    // flush what the previous panel launch parked (nobody reads those blocks in this launch): one diagonal factor, or
+    // after a 128-column launch (panel_pair.h) two diagonal factors and L21
+    panel_flush_duties<TS>(W, ld, lpark, lpark21, prev_c0, prev2_c0, prev21_c0, tid);
     double PD[4][4];
     double PT[16];
 #pragma unroll

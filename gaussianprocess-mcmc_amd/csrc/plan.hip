@@ -34,7 +34,7 @@ static PlanLayout plan_layout(int n, int d, int es) {
     L.off_hyp = take((size_t)(2 + PLAN_MAXD) * es);
     L.off_out = take(4 * sizeof(double));
     L.off_info = take(sizeof(int));
-    L.off_scratch = take((size_t)(L.np_ / NB_IN + 1) * (1024 + 4096) * sizeof(double));
+    L.off_scratch = take((size_t)(L.np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double));
     L.total = o;
     return L;
 }
@@ -106,7 +106,7 @@ extern "C" {
 int gpmc_version(void) { return GPMC_VERSION; }
 const char* gpmc_last_error(void) { return g_err; }
 int gpmc_pad(int n) { return round_up(n, GPMC_PAD); }
-size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096) * sizeof(double); }
+size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
 
 int gpmc_set_option(const char* name, int value) {
     if (!name) return fail(-1, "gpmc_set_option: null name");
@@ -123,6 +123,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "la_min_m")) g_opt.la_min_m = value;
     else if (!strcmp(name, "la_min_np")) g_opt.la_min_np = value;
     else if (!strcmp(name, "la_nb128_m")) g_opt.la_nb128_m = value;
+    else if (!strcmp(name, "panel_pair")) g_opt.panel_pair = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "panel_prio")) g_opt.panel_prio = value ? 1 : 0;
     else if (!strcmp(name, "la_order")) g_opt.la_order = value ? 1 : 0;
     else if (!strcmp(name, "la_depth")) g_opt.la_depth = (value == 2) ? 2 : 1;
@@ -151,6 +152,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "la_depth")) return g_opt.la_depth;
     if (!strcmp(name, "la_order")) return g_opt.la_order;
     if (!strcmp(name, "panel_prio")) return g_opt.panel_prio;
+    if (!strcmp(name, "panel_pair")) return g_opt.panel_pair;
     if (!strcmp(name, "gemm_8wave")) return g_opt.gemm_8wave;
     if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;
     if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;

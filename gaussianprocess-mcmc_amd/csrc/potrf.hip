@@ -25,6 +25,7 @@
 #include "diag_mp.h"
 #include "panel_fused.h"
 #include "panel_fused2.h"
+#include "panel_pair.h"
 #include "gemm4.h"
 #include "gemm4p.h"
 
@@ -476,8 +477,14 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
 }
 
 // factor the outer panel at k0 (nbk columns, rows k0..mp): inner left-looking loop of 64-column blocks
+// what the last fused panel launch left parked in scratch, to be flushed into W by the next one (or by the final flush)
+struct Parked {
+    int d0 = -1, d1 = -1, l21 = -1;   // diagonal factors at columns d0, d1; L21 of the 128-column launch at l21
+};
+
 template <typename T>
-static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s) {
+static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s,
+                        Parked& pk, double* lpark21, bool beside_gemm) {
     if (g_opt.panel_impl == 2) {   // fused kernel with in-block look-ahead: 5 waves, wave 4 = serial micro-panel factor
         static bool attr2_done = false;   // per T instantiation
         if (!attr2_done) {
@@ -499,10 +506,31 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
             attr_done = true;
         }
-        for (int c0 = k0; c0 < k0 + nbk; c0 += NB_IN) {
-            hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s,
-                               W, ld, k0, c0, info_dev, lpark, c0 - NB_IN, (unsigned long long*)nullptr, g_opt.panel_prio);
-            GPMC_LAUNCH_CHECK();
+        static bool attrp_done = false;   // per T instantiation
+        if (!attrp_done) {
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_pair_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairShared)));
+            attrp_done = true;
+        }
+        for (int c0 = k0; c0 < k0 + nbk;) {
+            // panel_pair = 1: only beside the trailing GEMM (look-ahead), where every panel LAUNCH pays a CU-slot wait of
+            // ~40 us and one launch for 128 columns halves that; alone on the chip the pair launch takes exactly as long
+            // as the two launches it replaces (43-45 vs 18.6 + 23.7 us).  2: everywhere.
+            if ((g_opt.panel_pair >= 2 || (g_opt.panel_pair == 1 && beside_gemm)) && c0 == k0 && nbk >= 2 * NB_IN) {
+                // the first 128 columns of the outer panel in one launch (panel_pair.h)
+                hipLaunchKernelGGL((panel_pair_kernel<T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PairShared), s, W, ld,
+                                   c0, info_dev, lpark, lpark21, pk.d0, pk.d1, pk.l21, g_opt.panel_prio);
+                GPMC_LAUNCH_CHECK();
+                pk.d0 = c0 + NB_IN; pk.d1 = c0; pk.l21 = c0;
+                c0 += 2 * NB_IN;
+            } else {
+                hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared),
+                                   s, W, ld, k0, c0, info_dev, lpark, pk.d0, (unsigned long long*)nullptr,
+                                   g_opt.panel_prio, lpark21, pk.d1, pk.l21);
+                GPMC_LAUNCH_CHECK();
+                pk.d0 = c0; pk.d1 = -1; pk.l21 = -1;
+                c0 += NB_IN;
+            }
         }
         return 0;
     }
@@ -553,10 +581,16 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     auto mp_at = [&](int kend) { return ntri > 0 ? mp - ntri + (kend < ntri ? kend : ntri) : mp; };
     T* dinv = reinterpret_cast<T*>(scratch);
     double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
+    double* lpark21 = lpark + (size_t)(np_ / NB_IN + 1) * 4096;
     const bool fused = (g_opt.panel_impl >= 1);
+    Parked pk;
     auto final_flush = [&]() -> int {
         if (!fused) return 0;
-        hipLaunchKernelGGL((panel_flush_kernel<T>), dim3(1), dim3(256), 0, s, W, ldw, lpark, np_ - NB_IN);
+        if (g_opt.panel_impl == 1) {   // whatever the last launch parked: one or two diagonal factors and L21
+            hipLaunchKernelGGL((panel_flush3_kernel<T>), dim3(3), dim3(256), 0, s, W, ldw, lpark, lpark21, pk.d0, pk.d1, pk.l21);
+        } else {
+            hipLaunchKernelGGL((panel_flush_kernel<T>), dim3(1), dim3(256), 0, s, W, ldw, lpark, np_ - NB_IN);
+        }
         GPMC_LAUNCH_CHECK();
         return 0;
     };
@@ -588,7 +622,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     auto serial_from = [&](int kstart, int nbs) -> int {
         for (int k0 = kstart; k0 < np_; k0 += nbs) {
             const int nbk = (np_ - k0 < nbs) ? np_ - k0 : nbs;
-            int rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s);
+            int rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s, pk, lpark21, false);
             if (rc) return rc;
             const int k1 = k0 + nbk;
             if (k1 < np_) {
@@ -629,7 +663,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             GPMC_HIP(hipEventRecord(ef, s));
             GPMC_HIP(hipStreamWaitEvent(ps, ef, 0));
             const int nbk = (np_ < NB) ? np_ : NB;
-            int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, ps);
+            int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, ps, pk, lpark21, false);
             if (rc) return rc;
             pe_prev = next_ev();
             GPMC_HIP(hipEventRecord(pe_prev, ps));
@@ -657,7 +691,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (ge_prev) GPMC_HIP(hipStreamWaitEvent(ps, ge_prev, 0));
             int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, ps, k1, k2, true);
             if (rc) return rc;
-            rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k2), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
+            rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k2), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps, pk, lpark21, true);
             if (rc) return rc;
             hipEvent_t pe_next = next_ev();
             GPMC_HIP(hipEventRecord(pe_next, ps));
@@ -677,7 +711,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     int nbk = la_nb(np_);
     if (nbk > np_) nbk = np_;
     {
-        int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, s);
+        int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, s, pk, lpark21, false);
         if (rc) return rc;
     }
     for (int k0 = 0, nb_next = 0; k0 < np_; k0 += nbk, nbk = nb_next) {
@@ -709,7 +743,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         }
         // (2) factor next panel on ps
         GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
-        rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k1 + nbn), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps);
+        rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k1 + nbn), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps, pk, lpark21, true);
         if (rc) return rc;
         hipEvent_t e2 = next_ev();
         GPMC_HIP(hipEventRecord(e2, ps));
@@ -796,7 +830,7 @@ int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev,
     GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true, double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
     hipLaunchKernelGGL((panel_block_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W,
-                       ld, k0, c0, info_dev, lpark, -1, dbg_dev, 0);
+                       ld, k0, c0, info_dev, lpark, -1, dbg_dev, 0, (const double*)nullptr, -1, -1);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
