@@ -254,7 +254,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
                        'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
-                       'schedule': 'auto (look-ahead NB=256 while >3072 columns remain, then serial NB=128)',
+                       'schedule': 'auto (look-ahead NB=256 while >2048 columns remain, then serial NB=128)',
                        'launch': 'hipGraph replay'},
             'roofline': {'bound': 'mfma', 'kernel': 'gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)',
                          'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',

@@ -36,10 +36,11 @@ struct Options {
     // ---- schedule (defaults = the auto rules of potrf())
     int outer_nb = 0;         // outer block of the right-looking Cholesky (multiple of 128); 0 = auto: 128 serial (f32: f32_nb
                               // from np_ 4096), under look-ahead 256 / 384 / 512 by remaining columns
-    int lookahead = -1;       // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: np_ >= 6144
-    int la_min_np = 6144;     // auto look-ahead from this padded size on
+    int lookahead = -1;       // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: np_ >= la_min_np
+    int la_min_np = 4096;     // auto look-ahead from this padded size on (4096: 2.25 -> 2.10 ms, 5120: 3.16 -> 2.88; 3072: no gain)
     int la_nb128_m = 0;       // under look-ahead: outer block 128 once fewer columns than this remain (0 = never)
-    int la_min_m = 3072;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
+    int la_min_m = 2048;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
+                              // (2048 vs 3072 with the 128-column panel launch: 8192 6.41 vs 6.51 ms, 6144 3.83 vs 3.88)
     int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (measured slower)
     int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first (measured slower)
     int panel_pair = 1;       // first 128 columns of an outer panel in one launch (panel_pair.h): 0 never, 1 under look-ahead

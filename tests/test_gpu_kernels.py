@@ -251,7 +251,7 @@ def test_large_size_schedule_options_agree(gp):
     hyp = [1.2, 9.0, 1.1]
     gpmc = gp['gpmc']
     base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024}
-    reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 3072, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
+    reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 2048, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
              'panel_prio': 0, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_persistent': 0, 'gemm_8wave': 0,
              'gemm_small_bk32': 0}
     variants = (('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('prio', {'panel_prio': 1}),
