@@ -46,6 +46,8 @@ struct Options {
     int panel_pair = 1;       // first 128 columns of an outer panel in one launch (panel_pair.h): 0 never, 1 under look-ahead
                               // (6144: 3.96 -> 3.83 ms, 8192: 6.69 -> 6.50, 12288: -1.3 %, f32 16384: -2.3 %), 2 everywhere
                               // (serial phases: +1.7 % at 2048 / 4096)
+    int panel_lds_pad = 0;    // extra LDS bytes requested by the 64-column panel kernel beside the GEMM; 16384+ makes it wait
+                              // for an empty CU instead of sharing one: 8192 6.58 vs 6.41 ms, 16384 33.6 vs 32.8 -> stays 0
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
     int use_graph = 1;        // capture the plan's launch sequence into a hipGraph
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles

@@ -21,11 +21,12 @@
 
 namespace gpmc {
 
-// LDS: four 64 x 64 buffers, 152 KB -- a workgroup of this kernel needs a completely free CU.  That is deliberate: a
-// two-buffer variant (X1 kept in registers as the update's B operand, T2 loaded from global in register form; 79 KB,
-// 212 VGPRs, able to slot in beside one GEMM workgroup like the 64-column kernel) was correct but gave the gain back
-// (N = 8192: 6.69 vs 6.46 ms, 4096: 2.19 vs 2.09) -- a panel workgroup sharing its CU with a GEMM workgroup runs
-// slower than one that waits for an empty CU, as the CU-sharing experiment in DESIGN.md already showed.
+// LDS: four 64 x 64 buffers, 152 KB -- a workgroup of this kernel needs a completely free CU.  A two-buffer variant
+// (X1 kept in registers as the update's B operand, T2 loaded from global in register form; 79 KB, 212 VGPRs, able to
+// slot in beside one GEMM workgroup like the 64-column kernel) was correct but slower in itself (N = 2048, alone:
+// 0.968 vs 0.922 ms) and gave the look-ahead gain back (N = 8192: 6.69 vs 6.46 ms, 4096: 2.19 vs 2.09).  Whether a
+// panel workgroup shares a CU or waits for an empty one is not what decides: padding the 64-column kernel's LDS
+// request so that it, too, needs an empty CU (panel_lds_pad) loses 2-3 % (8192: 6.58 vs 6.41 ms).
 struct PairShared {
     double A[64][MP_LD];      // Lout of factor 1, later of factor 2
     double S[64][MP_LD];      // S21 in;  L21 as [row][k] after its solve (in place)

@@ -124,6 +124,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "la_min_np")) g_opt.la_min_np = value;
     else if (!strcmp(name, "la_nb128_m")) g_opt.la_nb128_m = value;
     else if (!strcmp(name, "panel_pair")) g_opt.panel_pair = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "panel_lds_pad")) g_opt.panel_lds_pad = value < 0 ? 0 : value;
     else if (!strcmp(name, "panel_prio")) g_opt.panel_prio = value ? 1 : 0;
     else if (!strcmp(name, "la_order")) g_opt.la_order = value ? 1 : 0;
     else if (!strcmp(name, "la_depth")) g_opt.la_depth = (value == 2) ? 2 : 1;
@@ -152,6 +153,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "la_depth")) return g_opt.la_depth;
     if (!strcmp(name, "la_order")) return g_opt.la_order;
     if (!strcmp(name, "panel_prio")) return g_opt.panel_prio;
+    if (!strcmp(name, "panel_lds_pad")) return g_opt.panel_lds_pad;
     if (!strcmp(name, "panel_pair")) return g_opt.panel_pair;
     if (!strcmp(name, "gemm_8wave")) return g_opt.gemm_8wave;
     if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;

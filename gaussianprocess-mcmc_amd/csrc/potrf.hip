@@ -503,7 +503,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
         static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
             GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<false, T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done = true;
         }
         static bool attrp_done = false;   // per T instantiation
@@ -524,7 +524,10 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
                 pk.d0 = c0 + NB_IN; pk.d1 = c0; pk.l21 = c0;
                 c0 += 2 * NB_IN;
             } else {
-                hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared),
+                // beside the GEMM an LDS request above 90,112 B (= 163,840 - one 73,728 B GEMM workgroup) makes the
+                // panel workgroup wait for an EMPTY CU instead of sharing one (panel_lds_pad, see gpmc_common.h)
+                const size_t psm = sizeof(PanelShared) + (beside_gemm ? (size_t)g_opt.panel_lds_pad : 0);
+                hipLaunchKernelGGL((panel_block_kernel<false, T>), dim3((mp - c0) / NB_IN), dim3(256), psm,
                                    s, W, ld, k0, c0, info_dev, lpark, pk.d0, (unsigned long long*)nullptr,
                                    g_opt.panel_prio, lpark21, pk.d1, pk.l21);
                 GPMC_LAUNCH_CHECK();
