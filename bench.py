@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- GP log-marginal evals/sec (= slice-sample steps/sec) on MI355X.
+"""bench.py -- GP log-marginal evals/sec on MI355X (BASELINE.json's metric).
 
-One "step" = one evaluation of log N(g; 0, K(hyp) + S) at fresh hyper-parameters on the workload
-BASELINE.json's metric is quoted on: RBF kernel, N = 8192, d = 2, fp64, synthetic (X, g) resident in HBM
-(SURVEY.md 8(d)): K build + S diagonal + blocked Cholesky with g riding + reduction, scalar + info back to
-the host.  Evaluations are issued back to back on one stream with distinct hyper-parameters cycled from 16
-points drawn from the sampler's bracket; nothing is cached between steps.
+One "step" = ONE evaluation of log N(g; 0, K(hyp) + S) at fresh hyper-parameters = what the slice sampler
+re-evaluates for one hyper-parameter proposal's log-marginal term (kcMCMC/sliceSample.py:136-137,196,147): K build
++ S diagonal + blocked Cholesky with g riding + reduction, N^3/3 flops, scalar + info back on the host.  It is NOT a
+full SDS proposal (4 N^3/3 here, two factorisations) nor a sampler iteration (several proposals): those rates are the
+`--full` extras `sds_proposals_per_s` and `chain.iterations_per_s`.  Workload: RBF kernel, N = 8192, d = 2, fp64,
+synthetic (X, g) resident in HBM (SURVEY.md 8(d) / BASELINE.md 2), hyper-parameters cycled over 16 points drawn from
+the sampler's bracket; nothing is cached between steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--no-cpu] [--sds] [--sds-cpu] [--chain K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 2] [--pipelined] [--no-cpu] [--no-cpu-ref]
+                    [--metric-only] [--full | --sds --sds-cpu --chain K]
 
---sds adds to "extra" the rate of FULL surrogate-data-slice proposals (K, chol(K+S),
-V = L^-1 K, R = K - V^T V, m, chol R, f', log-marginal) on the same inputs; --sds-cpu (implies --sds) also times ONE
-proposal in the reference's literal op sequence on the host (oracle restatement; about a minute at N=8192).  Both are
-off by default so that the default command launches nothing but the metric's kernels (the committed rocprofv3
-kernel stats are of that command).
+Timed region: K steps, each one read back (logml, info) BEFORE the next is enqueued -- the way the sampler consumes
+them (sliceSample.py:154 branches on every value).  `--pipelined` times the back-to-back form instead; the default run
+reports the other form's rate in `extra.pipelined_evals_per_s`.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs its own independent chain-shaped
-stream of evaluations on its own GPU (weak scaling, no data-path collective); rank 0 prints ONE JSON line with
-the whole-job rate = total evaluations / max-over-ranks time.
+--gpus N > 1: when not already under torch.distributed.run, this script spawns N ranks of itself (one per GPU,
+LOCAL_RANK = 0..N-1, rendez-vous on 127.0.0.1) BEFORE anything touches the GPU in the parent, and forwards rank 0's
+JSON line.  Every rank runs its own independent stream of evaluations on its own GPU with its own inputs (seed
+124 + rank): weak scaling, no data-path collective; value = N * K / max-over-ranks time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,14 +37,71 @@ sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TF = 78.6      # AMD MI355X spec, FP64 matrix (= vector); measured instruction ceilings in DESIGN.md
 HBM_PEAK_GBS = 8000.0
+RING = 32                       # result slots the timed loops cycle through (the plan has 64)
 
 
-def synth_inputs(n, d, seed=124, truth=(1.0, 10.0, 1.2), npoints=16, scale=(10., 10., 5.)):
-    """X ~ U(0,10)^(n x d); g ~ N(0, 25 I) stands in for the GP draw (the cost of an evaluation does not depend
-    on g); 16 hyper-parameter points from the sampler's bracket [max(h - U(0,s), 0), +s], floored at 0.05."""
+# ------------------------------------------------------------------------------------------ multi-rank launch
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU.  The parent never
+    initialises the GPU (it imports neither torch nor gpmc); it forwards rank 0's stdout and fails if any rank fails."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:       # rank 0 is done (or dead) and this one is not: stop it by PID
+            p.kill()
+            rcs.append(p.wait())
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        raise SystemExit('bench.py: ranks failed (rank, exit code): %r' % bad)
+
+
+# ------------------------------------------------------------------------------------------ inputs
+def effective_cpus():
+    """cores this process may really use: min(affinity mask, cgroup cpu.max quota) -- the GPU boxes expose 128 logical
+    CPUs but grant a 1-GPU job a share of 16, and a BLAS pool sized to 128 there runs ~10x slower than one sized 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, p = fh.read().split()
+        if q != 'max':
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def synth_inputs(n, d, seed=124, truth=(1.0, 10.0, 1.2), npoints=16, scale=(10., 10., 5.), threads=None):
+    """BASELINE.md 2: RandomState(124 + rank); X ~ U(0,10)^(n x d); truth (ll, sf, sn) = (1, 10, 1.2);
+    g = chol(K + sn^2 I) z (host SciPy, outside every timed region); 16 hyper-parameter points from the sampler's
+    bracket [max(h - U(0,s), 0), +s] (framework.py:69 scale), floored at 0.05."""
+    import scipy.linalg
+    from scipy.spatial.distance import cdist
+    from threadpoolctl import threadpool_limits
     rng = np.random.RandomState(seed)
     X = rng.uniform(0., 10., (n, d))
-    g = rng.standard_normal(n) * 5.0
+    z = rng.standard_normal(n)
+    with threadpool_limits(limits=threads):
+        K = cdist(X / truth[0], X / truth[0], 'sqeuclidean')
+        K *= -0.5
+        np.exp(K, out=K)
+        K *= truth[1] ** 2
+        K[np.diag_indices(n)] += truth[2] ** 2
+        L = scipy.linalg.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+        g = L @ z
+    del K, L
     h, s = np.asarray(truth), np.asarray(scale)
     pts = []
     for _ in range(npoints):
@@ -69,24 +130,127 @@ def pmc_traffic(n, kernel_prefix='gpmc::gemm4_nt_kernel'):
     return (num / den if den else None), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(X, g, pts, budget_s=20.0):
-    """B-lean of BASELINE.md: the oracle's SciPy path (cdist+exp, dpotrf, dtrsv) on the host cores, bounded sample."""
-    from oracle import sds_ref
+# ------------------------------------------------------------------------------------------ CPU baselines
+def blas_info():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+        return [{k: p.get(k) for k in ('user_api', 'internal_api', 'version', 'num_threads', 'threading_layer')}
+                for p in threadpool_info()]
     except Exception:
-        threads = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    vals, k = [], 0
-    while True:
-        vals.append(sds_ref.gp_log_marginal(X, g, pts[k % len(pts)]))
-        k += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or k >= 8:
-            break
+        return None
+
+
+def cpu_baseline(X, g, pts, threads, budget_s=20.0):
+    """B-lean of BASELINE.md: the oracle's SciPy path on the host cores, bounded sample, with the seconds of each
+    phase (K build = cdist + exp + S diagonal; dpotrf; dtrsv + reduction) timed on the last evaluation."""
+    import scipy.linalg
+    from threadpoolctl import threadpool_limits
+    from oracle import sds_ref
+    from oracle.kcgp_ref import covK as ref_covK
+    n = X.shape[0]
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        vals, k = [], 0
+        while True:
+            vals.append(sds_ref.gp_log_marginal(X, g, pts[k % len(pts)]))
+            k += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or k >= 8:
+                break
+        # one more evaluation, phase by phase (the same calls gp_log_marginal makes)
+        h = pts[0]
+        p0 = time.perf_counter()
+        K = ref_covK.RBF(np.log(h[0]), np.log(h[1])).getCovMatrix(x=X, mode='train')
+        K[np.diag_indices(n)] += sds_ref.s_diag(np.diagonal(K).copy(), h[2])
+        p1 = time.perf_counter()
+        L = scipy.linalg.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+        p2 = time.perf_counter()
+        sds_ref.log_marginal_lean(g, L)
+        p3 = time.perf_counter()
+        del K, L
     return dict(value=k / el, unit='evals/s', cores=int(threads), kind='port',
-                sample='%d evaluations of the same N=%d workload (first hyper-parameter points), %.1f s' % (k, X.shape[0], el)), vals
+                sample='%d evaluations of the same N=%d workload (first hyper-parameter points), %.1f s' % (k, n, el),
+                phase_seconds={'kbuild_cdist_exp': p1 - p0, 'dpotrf': p2 - p1, 'dtrsv_reduce': p3 - p2},
+                dpotrf_gflops=n ** 3 / 3.0 / max(p2 - p1, 1e-9) / 1e9, blas=blas_info(),
+                host_logical_cpus=os.cpu_count()), vals
+
+
+def cpu_baseline_ref(X, g, pts, threads, cap_s=150.0):
+    """B-ref of BASELINE.md: ONE proposal in the reference's literal op sequence (sliceSample.py:136-147,165-207:
+    dense S, dpotrf, np.linalg.solve on a triangle, np.dot, inv(S), dpotrf, inv(K+S)) through the oracle restatement.
+    ~11.3 N^3 flops: timed at N first on a 2048-point slice; if that predicts more than cap_s at full N the sample is
+    the 4096-point slice instead, and says so."""
+    from threadpoolctl import threadpool_limits
+    from oracle import sds_ref
+    from oracle.kcgp_ref import covK as ref_covK
+    n = X.shape[0]
+
+    def one(m):
+        Xm, gm, h = X[:m], g[:m], pts[0]
+        t0 = time.perf_counter()
+        Kc = ref_covK.RBF(np.log(h[0]), np.log(h[1])).getCovMatrix(x=Xm, mode='train')
+        _, K_S, m_, C_, L_ = sds_ref.aux_var_model_literal(np.zeros(m), Kc, h[2], gm)
+        _ = np.dot(C_, np.zeros(m)) + m_
+        _ = sds_ref.log_marginal_literal(gm, K_S, L_)
+        return time.perf_counter() - t0
+
+    with threadpool_limits(limits=threads):
+        probe_n = min(n, 2048)
+        t_probe = one(probe_n)
+        predicted = t_probe * (n / probe_n) ** 3
+        if n > probe_n and predicted <= cap_s:
+            m, t = n, one(n)
+        elif n > probe_n:
+            m = min(n, 4096)
+            t = one(m)
+        else:
+            m, t = probe_n, t_probe
+    return dict(value=1.0 / t, unit='SDS proposals/s (reference op sequence, ~11.3 N^3 flops)', seconds_per_proposal=t,
+                cores=int(threads), kind='port', n_sample=m,
+                sample='one literal proposal at N=%d%s' % (m, '' if m == n else
+                                                          ' (full N=%d predicted %.0f s from the N=%d probe: over the %.0f s cap)'
+                                                          % (n, predicted, probe_n, cap_s)))
+
+
+# ------------------------------------------------------------------------------------------ the work
+class StubPlan(object):
+    """GPMC_BENCH_STUB=1: no GPU, no library -- only so that the multi-rank plumbing of this script (spawn,
+    rendez-vous, barriers, max-over-ranks, one JSON line) can be tested on CPU with gloo.  Never a measurement."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def eval_async(self, hyp, slot=0):
+        time.sleep(1e-3)
+
+    def result(self, slot=0):
+        return (-1.0, 0.0, 0.0, 0)
+
+    def drain(self):
+        return {}
+
+    def close(self):
+        pass
+
+
+def timed_steps(plan, pts, steps, pipelined):
+    """K steps; returns the last result.  sync-each: read step i before enqueuing i+1.  pipelined: back to back on the
+    ring of result slots (a slot is read -- long complete -- before it is re-armed)."""
+    last = None
+    if pipelined:
+        for i in range(steps):
+            if i >= RING:
+                last = plan.result(i % RING)
+            plan.eval_async(pts[i % len(pts)], i % RING)
+        for i in range(max(steps - RING, 0), steps):
+            last = plan.result(i % RING)
+    else:
+        for i in range(steps):
+            plan.eval_async(pts[i % len(pts)], 0)
+            last = plan.result(0)
+            if last[3] != 0:
+                raise SystemExit('factorisation reported info=%d at step %d' % (last[3], i))
+    return last
 
 
 def main():
@@ -96,26 +260,43 @@ def main():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--n', type=int, default=8192)
     ap.add_argument('--d', type=int, default=2)
-    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--pipelined', action='store_true', help='time back-to-back enqueues instead of read-each-step')
+    ap.add_argument('--no-cpu', action='store_true', help='skip both host baselines')
+    ap.add_argument('--no-cpu-ref', action='store_true', help='skip the literal-sequence host baseline (B-ref)')
+    ap.add_argument('--metric-only', action='store_true',
+                    help='launch nothing but the metric\'s kernels (for rocprofv3 runs): no host baselines, no extras')
+    ap.add_argument('--full', action='store_true', help='= --sds --sds-cpu --chain 10')
     ap.add_argument('--sds', action='store_true', help='also time full SDS proposals (reported in "extra")')
-    ap.add_argument('--sds-cpu', action='store_true', help='also time one literal reference-sequence proposal on the host')
+    ap.add_argument('--sds-cpu', action='store_true', help='(kept for compatibility; B-ref is in the default line)')
     ap.add_argument('--chain', type=int, default=0, metavar='K',
                     help='also run K iterations of the real sampler (surrogate_slice_sampling) on these inputs: iterations/s')
     a = ap.parse_args()
+    if a.full:
+        a.sds, a.chain = True, (a.chain or 10)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(a.gpus, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
-    import gpmc
-    from gpmc import _lib, chains, core
-
-    if not torch.cuda.is_available():
+    stub = os.environ.get('GPMC_BENCH_STUB') == '1'
+    from gpmc import chains
+    if not stub and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the gpmc product path has no CPU fallback)')
     rank, world = chains.init_distributed()          # binds cuda:LOCAL_RANK first, then joins the RCCL group
-    dev = torch.device('cuda', torch.cuda.current_device())
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    dev = None if stub else torch.device('cuda', torch.cuda.current_device())
+    threads = max(1, effective_cpus() // world)
 
-    X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank)
-    # timed region: the plan's default path (the per-evaluation launch sequence replayed as a hipGraph)
-    plan = core.LogMarginalPlan(X, g, 'rbf')
+    if stub:
+        rng = np.random.RandomState(124 + rank)
+        X, g, pts = rng.uniform(0, 10, (a.n, a.d)), rng.standard_normal(a.n), rng.uniform(0.5, 5., (16, 3))
+        plan = StubPlan(a.n)
+    else:
+        import gpmc
+        from gpmc import _lib, core
+        X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank, threads=threads)
+        plan = core.LogMarginalPlan(X, g, 'rbf')   # default path: the launch sequence recorded once, replayed per step
 
     nccl = world > 1 and dist.get_backend() == 'nccl'
 
@@ -125,57 +306,64 @@ def main():
                 dist.barrier(device_ids=[dev.index])
             else:
                 dist.barrier()
-        torch.cuda.synchronize()
+        if dev is not None:
+            torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        plan.eval_async(pts[i % len(pts)], i % 32)
-    plan.result((a.warmup - 1) % 32 if a.warmup else 0)
-
+    timed_steps(plan, pts, a.warmup, a.pipelined)
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        plan.eval_async(pts[i % len(pts)], i % 32)
-    last = plan.result((a.steps - 1) % 32)
+    last = timed_steps(plan, pts, a.steps, a.pipelined)
     barrier()
     dt = time.perf_counter() - t0
-    if last[3] != 0:
+    if last is not None and last[3] != 0:
         raise SystemExit('factorisation reported info=%d' % last[3])
 
-    # roofline pass: the SAME K steps again with eager launches, every launch of the dominant kernel (trailing
-    # SYRK update) bracketed by HIP events recorded on the stream it is launched on.  A graph replay exposes no
-    # per-kernel boundaries to events, hence the second pass; its wall time is reported as ms_per_step_instrumented.
-    plan.close()
-    gpmc.set_option('use_graph', 0)
-    plan = core.LogMarginalPlan(X, g, 'rbf')
-    for i in range(min(a.warmup, 2)):
-        plan.eval_async(pts[i % len(pts)], i % 32)
-    plan.result(0)
-    torch.cuda.synchronize()
-    _lib.profile_begin()
+    # the other enqueue form, same K steps (reported beside the headline, never as `value`)
+    timed_steps(plan, pts, min(a.warmup, 2), not a.pipelined)
+    if dev is not None:
+        torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for i in range(a.steps):
-        plan.eval_async(pts[i % len(pts)], i % 32)
-    plan.result((a.steps - 1) % 32)
-    torch.cuda.synchronize()
-    dt_instr = time.perf_counter() - t1
-    k_ms, k_launches, k_flops = _lib.profile_read()
+    timed_steps(plan, pts, a.steps, not a.pipelined)
+    if dev is not None:
+        torch.cuda.synchronize()
+    dt_other = time.perf_counter() - t1
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or world == 1) else 'cpu')
+    k_ms = k_launches = k_flops = 0.0
+    dt_instr = 0.0
+    if not stub:
+        # roofline pass: the SAME K steps again with eager launches, every launch of the dominant kernel (trailing
+        # SYRK update) bracketed by HIP events recorded on the stream it is launched on.  A graph replay exposes no
+        # per-kernel boundaries to events, hence the second pass; its wall time is ms_per_step_instrumented.
+        plan.close()
+        gpmc.set_option('use_graph', 0)
+        plan = core.LogMarginalPlan(X, g, 'rbf')
+        timed_steps(plan, pts, min(a.warmup, 2), True)
+        torch.cuda.synchronize()
+        _lib.profile_begin()
+        t1 = time.perf_counter()
+        timed_steps(plan, pts, a.steps, True)
+        torch.cuda.synchronize()
+        dt_instr = time.perf_counter() - t1
+        k_ms, k_launches, k_flops = _lib.profile_read()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or (world == 1 and dev is not None)) else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
 
-    # parity of the timed path against the oracle on this rank's first points (checker, outside the timed region)
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu:          # the host baseline is timed at N = 1 only
-        cpu, vals = cpu_baseline(X, g, pts)
+    # host baselines (rank 0, N = 1 only) + parity of the timed path against the oracle on this rank's first points
+    cpu = cpu_ref = None
+    if rank == 0 and world == 1 and not stub and not a.no_cpu and not a.metric_only:
+        cpu, vals = cpu_baseline(X, g, pts, threads)
         for j, v in enumerate(vals[:2]):
             got = plan(pts[j])
             if abs(got - v) > 1e-8 * abs(v):
                 raise SystemExit('parity failure vs SciPy at point %d: %r vs %r' % (j, got, v))
+        if not a.no_cpu_ref:
+            cpu_ref = cpu_baseline_ref(X, g, pts, threads)
 
     extra = {}
-    if rank == 0:
+    if rank == 0 and not stub and not a.metric_only:
         # the O(N^2) kernel build alone, against its HBM roofline (bytes = s N^2 written + s N d read;
         # the lower-only build the plan uses is reported against the same s N^2, and says so)
         from gpmc import ops
@@ -199,7 +387,7 @@ def main():
                                       'frac_of_hbm_peak': kb_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         extra['kbuild_lower_only']['note'] = 'writes only the tiles touching the lower triangle; rate quoted against the full s*N^2 bytes'
         del Wk
-    if (a.sds or a.sds_cpu) and rank == 0:
+    if a.sds and rank == 0 and not stub:
         from gpmc import sds
         ws = sds.SDSWorkspace(X)
         f = torch.zeros(a.n, dtype=torch.float64, device=dev)
@@ -216,19 +404,7 @@ def main():
         extra['sds_proposals_per_s'] = reps / (time.perf_counter() - t1)
         extra['sds_flops_per_proposal'] = 4.0 * a.n ** 3 / 3.0     # inverse form (gpmc/sds.py)
         del ws
-        if a.sds_cpu:
-            # the reference's literal op sequence (sliceSample.py:136-147,165-207) through the oracle restatement
-            from oracle import sds_ref
-            from oracle.kcgp_ref import covK as ref_covK
-            h = pts[0]
-            t1 = time.perf_counter()
-            Kc = ref_covK.RBF(np.log(h[0]), np.log(h[1])).getCovMatrix(x=X, mode='train')
-            _, K_S, m_, C_, L_ = sds_ref.aux_var_model_literal(np.zeros(a.n), Kc, h[2], g)
-            _ = np.dot(C_, eta.cpu().numpy()) + m_
-            _ = sds_ref.log_marginal_literal(g, K_S, L_)
-            extra['sds_cpu_literal_s_per_proposal'] = time.perf_counter() - t1
-
-    if a.chain > 0 and rank == 0:
+    if a.chain > 0 and rank == 0 and not stub:
         # chain-level cross-check: the real sampler from the framework's initial point; targets are a
         # bounded series in the reference's data range, one aux_var_model + several full SDS proposals per iteration
         from gpmc import framework
@@ -246,16 +422,23 @@ def main():
     if rank == 0:
         value = world * a.steps / tmax
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(a.n) if a.d == 2 else (None, None)
+        traffic, traffic_src = pmc_traffic(a.n) if (a.d == 2 and not stub) else (None, None)
+        other = 'pipelined' if not a.pipelined else 'sync_each'
+        extra[other + '_evals_per_s'] = a.steps / dt_other          # this rank's own rate in the other enqueue form
         line = {
             'metric': 'GP log-marginal evals/sec (= slice-sample steps/sec) at N=%d' % a.n,
+            'metric_note': 'one step = ONE log-marginal evaluation (K build + Cholesky + reduction, N^3/3 flops), the unit '
+                           'SURVEY.md 8(d) defines; a full SDS proposal is 4x and a sampler iteration several proposals: '
+                           'see extra.sds_proposals_per_s / extra.chain with --full',
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * tmax / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (no GPU work; plumbing test only)',
             'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
                        'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
                        'schedule': 'auto (look-ahead NB=256 while >2048 columns remain, then serial NB=128)',
-                       'launch': 'hipGraph replay'},
+                       'launch': 'recorded sequence of linear hipGraphs, replayed',
+                       'enqueue': 'pipelined (back to back)' if a.pipelined else 'sync-each (result read before the next step)',
+                       'g': 'GP draw chol(K+sn^2 I) z at the truth hyper-parameters (BASELINE.md 2)'},
             'roofline': {'bound': 'mfma', 'kernel': 'gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)',
                          'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MATRIX_PEAK_TF,
@@ -266,8 +449,9 @@ def main():
                          'measured_in': 'second pass over the same steps, eager launches, HIP events on the launch stream',
                          'ms_per_step_instrumented': 1e3 * dt_instr / a.steps,
                          'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (PMC)',
-                         'traffic_source': traffic_src},
+                         'traffic_source': traffic_src, 'traffic_measured_in_run': False},
             'cpu_baseline': cpu,
+            'cpu_baseline_ref': cpu_ref,
         }
         if extra:
             line['extra'] = extra

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/gpmc.h"
 
@@ -118,8 +119,9 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
            int rows_out, int cols_out, int ldk, int flags, hipStream_t s);
+struct Sched;
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0);
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0, Sched* sc = nullptr);
 template <typename T>
 int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s);
 template <typename T>
@@ -142,13 +144,50 @@ int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStr
 template <typename T>
 int trmv_upper(const T* W, int n, int ldw, const T* x, const T* y0, double alpha, T* y, hipStream_t s);
 
-// look-ahead resources (second stream + events), created lazily per process
-struct Aux {
-    hipStream_t panel_stream = nullptr;
-    hipEvent_t ev[16] = {};
-    bool ready = false;
+// ---------------------------------------------------------------- launch schedule of one factorisation
+// Where a factorisation's launches go: a main stream, a panel stream for the look-ahead, and the cross-stream edges
+// between them.  Three ways to run the same host code (potrf() only ever calls edge_record / edge_wait and launches
+// kernels on sc.main / sc.panel):
+//   EAGER     edges are hipEventRecord / hipStreamWaitEvent, kernels run as they are launched.
+//   SEGMENTS  (the plan's replay form) both streams are in stream capture; every edge CUTS the capture of the stream it
+//             touches, so the sequence becomes an op list  [linear graph | record | wait | linear graph | ...]  that
+//             replay() re-issues in order.  Every graph is single-stream: no exec ever owns internal branch streams.
+//             Why: on the HIP runtime bundled with the torch wheel (7.0.51831) destroying a FORK/JOIN exec after a
+//             device-wide sync is a use-after-free inside the runtime's signal-handler thread
+//             (amd::roc::VirtualGPU::updateCommandsState -> ReferenceCountedObject::release -> free(); same binary on
+//             runtime 7.2.26015: clean; scripts/graph_repro*.sh, profiles/r02_graph_abort_isolation.txt), the
+//             instantiation of such an exec sometimes serialises its branches, and the runtime picks the branch's
+//             hardware queue.  Linear graphs tied by our own events on our own two streams have none of the three.
+//   FORKJOIN  (diagnostic only: gpmc_debug_graph_churn) round 1's form, one graph with the panel stream forked in.
+struct SeqOp {
+    int kind;              // 0 graph launch, 1 event record, 2 stream wait
+    int on_panel;          // which stream: 0 main, 1 panel
+    hipGraphExec_t exec;
+    hipEvent_t ev;
 };
-int aux_get(Aux** out);
+struct Sched {
+    enum Mode { EAGER = 0, SEGMENTS = 1, FORKJOIN = 2 };
+    int mode = EAGER;
+    hipStream_t main = nullptr, panel = nullptr;
+    bool own_panel = false;
+    std::vector<hipEvent_t> events;      // EAGER / FORKJOIN: a ring; SEGMENTS: one event per edge
+    size_t ev_next = 0;
+    std::vector<SeqOp> ops;
+    bool cap_main = false, cap_panel = false;
+
+    int init(hipStream_t main_stream);                       // creates the panel stream and a first batch of events
+    int reserve_events(size_t n);
+    int edge_record(hipStream_t s, hipEvent_t* out);         // out = the event recorded on s
+    int edge_wait(hipStream_t s, hipEvent_t e);
+    int begin(int mode_);                                    // SEGMENTS / FORKJOIN: start capturing
+    int end();                                               // ... stop; the op list is complete
+    int replay();
+    int drop_ops();                                          // destroy the recorded graphs (plain destroys)
+    int destroy();                                           // + events and the panel stream
+  private:
+    int cut(hipStream_t s);
+};
+Sched* eager_sched(hipStream_t main_stream);   // process-wide EAGER schedule for the bare gpmc_potrf_* entry points
 int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, hipStream_t s);
 int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s);
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,

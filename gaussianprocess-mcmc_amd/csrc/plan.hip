@@ -3,9 +3,10 @@
 // One plan = one (kernel, n, d, dtype) problem bound to caller-owned device memory.  An evaluation is
 //   H2D(16..80 B of kernel parameters) -> [ kbuild(lower, S on the diagonal, identity padding)
 //   -> copy g into the riding row -> blocked Cholesky -> log-det / quadratic-form reduction ] -> D2H(32 B)
-// The bracketed part is a static launch sequence (~400 launches at N=8192, two streams for the
-// look-ahead); it is captured once into a hipGraph and replayed, so the host cost per evaluation is
-// one graph launch instead of hundreds of kernel launches.
+// The bracketed part is a static launch sequence (~200 launches at N=8192, two streams for the
+// look-ahead).  It is recorded once as a sequence of LINEAR hipGraphs cut at the cross-stream edges (gpmc_common.h,
+// `Sched`) and replayed: ~3 host calls per look-ahead step instead of hundreds of kernel launches, and no graph exec
+// that spans two streams.
 #include <cmath>
 #include <new>
 
@@ -48,16 +49,12 @@ struct gpmc_plan {
     hipStream_t stream;
     double* host_pin;     // PLAN_SLOTS x (2+MAXD) staged parameters (as T bytes) + PLAN_SLOTS x 4 results
     size_t hyp_slot_bytes;
-    hipGraph_t graph;
-    hipGraphExec_t exec;
+    gpmc::Sched sched;    // the plan's own panel stream, events and recorded launch sequence
+    bool recorded;
     int evals;
     bool have_data;
-    // graph validation (see gpmc_plan_logml_async): wall time of the eager first evaluation, and whether the
-    // instantiated graph has been checked against it / abandoned
-    hipEvent_t ev0, ev1;
-    float eager_ms;
-    bool graph_checked, graph_off;
-    int graph_retries;
+    unsigned char slot_busy[64];   // PLAN_SLOTS: 1 while an evaluation using the slot's staging / result is in flight
+    hipEvent_t slot_ev[64];        // recorded behind the slot's result copy
 };
 
 namespace gpmc {
@@ -75,26 +72,13 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
                        GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s);
     if (rc) return rc;
     GPMC_HIP(hipMemcpyAsync(W + (size_t)L.np_ * L.ld, g, (size_t)p->n * sizeof(T), hipMemcpyDeviceToDevice, s));
-    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s);
+    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched);
     if (rc) return rc;
     return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s);
 }
 
 static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
     return p->es == 8 ? plan_enqueue_body<double>(p, s) : plan_enqueue_body<float>(p, s);
-}
-
-// Retiring a graph exec.  ROCm 7.2: destroying an exec whose launch sequence spans two streams (the look-ahead
-// schedule) after a device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize()) has touched its
-// internal streams corrupts the runtime's heap -- scripts/graph_stress.py modes 3 and 7 abort within a few cycles,
-// single-stream graphs and destroys not preceded by a device sync (modes 0/1/4) never do.  One more replay followed
-// by a stream sync right before the destroy makes it safe (modes 8/9, 480 cycles clean), so every exec leaves this
-// way.  The replay recomputes the last evaluation into the plan's workspace, which must therefore still be valid.
-static void retire_exec(gpmc_plan* p) {
-    if (!p->exec) return;
-    if (hipGraphLaunch(p->exec, p->stream) == hipSuccess) (void)hipStreamSynchronize(p->stream);
-    (void)hipGraphExecDestroy(p->exec);
-    p->exec = nullptr;
 }
 
 }  // namespace gpmc
@@ -278,16 +262,23 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     p->kernel = kernel; p->n = n; p->d = d; p->es = elem_size; p->L = L;
     p->ws = reinterpret_cast<char*>(workspace);
     p->stream = S_(stream);
-    p->graph = nullptr; p->exec = nullptr; p->evals = 0; p->have_data = false;
-    p->ev0 = p->ev1 = nullptr; p->eager_ms = 0.f; p->graph_checked = false; p->graph_off = false; p->graph_retries = 0;
+    p->recorded = false; p->evals = 0; p->have_data = false;
+    memset(p->slot_busy, 0, sizeof(p->slot_busy));
+    memset(p->slot_ev, 0, sizeof(p->slot_ev));
+    {   // the plan's own look-ahead stream and one event per cross-stream edge of its schedule (2 per 128 columns
+        // bounds every schedule potrf() builds), created here, destroyed in gpmc_plan_destroy
+        int rc = p->sched.init(p->stream);
+        if (!rc) rc = p->sched.reserve_events((size_t)(2 * (L.np_ / GPMC_PAD) + 8));
+        if (rc) { (void)p->sched.destroy(); delete p; return rc; }
+    }
     p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD) * sizeof(double);
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p->host_pin),
                                  PLAN_SLOTS * (p->hyp_slot_bytes + 4 * sizeof(double)), hipHostMallocDefault);
-    if (e != hipSuccess) { delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
     // zero the riding rows once: only row np_ is ever rewritten (with g), the others stay zero
     e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
                        (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
-    if (e != hipSuccess) { (void)hipHostFree(p->host_pin); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
     *out = p;
     return 0;
 }
@@ -308,6 +299,10 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     const int need = 2 + (p->kernel == GPMC_KERNEL_RBF ? 1 : p->d);
     GPMC_ARG(kparams_host != nullptr && nk == need, 3);
     GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 4);
+    // a slot's pinned staging feeds an asynchronous H2D copy and its result lands asynchronously: re-arming it while
+    // its evaluation is still in flight would silently run the earlier evaluation with the later parameters
+    if (p->slot_busy[slot])
+        return fail(-4, "gpmc_plan_logml_async: slot %d still has an evaluation in flight (call gpmc_plan_result first)", slot);
     char* hslot = reinterpret_cast<char*>(p->host_pin) + (size_t)slot * p->hyp_slot_bytes;
     if (p->es == 8) {
         memcpy(hslot, kparams_host, (size_t)nk * sizeof(double));
@@ -317,122 +312,66 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     }
     GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)nk * p->es, hipMemcpyHostToDevice, p->stream));
     int rc = 0;
-    const bool graph_ok = g_opt.use_graph && !p->graph_off && p->stream != nullptr;   // the NULL stream cannot be captured
+    const bool graph_ok = g_opt.use_graph && p->stream != nullptr;   // the NULL stream cannot be captured
     if (!graph_ok || p->evals == 0) {
-        // first evaluation runs eagerly (creates streams, sets attributes) and is timed: the reference for the
-        // graph check below
-        const bool timeit = graph_ok && p->evals == 0;
-        if (timeit) {
-            if (!p->ev0) { GPMC_HIP(hipEventCreate(&p->ev0)); GPMC_HIP(hipEventCreate(&p->ev1)); }
-            GPMC_HIP(hipEventRecord(p->ev0, p->stream));
-        }
+        // eager launches; the first evaluation always (it sets the kernels' attributes, which a capture would record)
+        p->sched.mode = Sched::EAGER;
         rc = plan_enqueue(p, p->stream);
         if (rc) return rc;
-        if (timeit) {
-            GPMC_HIP(hipEventRecord(p->ev1, p->stream));
-            GPMC_HIP(hipEventSynchronize(p->ev1));
-            GPMC_HIP(hipEventElapsedTime(&p->eager_ms, p->ev0, p->ev1));
-        }
     } else {
-        if (!p->graph) {
-            GPMC_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-            rc = plan_enqueue(p, p->stream);
-            hipError_t e = hipStreamEndCapture(p->stream, &p->graph);
+        if (!p->recorded) {
+            rc = p->sched.begin(Sched::SEGMENTS);
             if (rc) return rc;
-            if (e != hipSuccess) return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            rc = plan_enqueue(p, p->stream);
+            const int rc2 = p->sched.end();
+            if (rc || rc2) { (void)p->sched.drop_ops(); return rc ? rc : rc2; }
+            p->recorded = true;
         }
-        if (!p->exec) GPMC_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
-        if (p->graph_checked) {
-            GPMC_HIP(hipGraphLaunch(p->exec, p->stream));
-        } else {
-            // Validate the instantiation once.  Observed on ROCm 7.2: hipGraphInstantiate does not always map the
-            // two-stream look-ahead schedule the same way -- about one exec in ten replays it with the branches
-            // serialised (13.5 ms instead of 6.7 ms at N=8192), one in six at 7.05 ms; each exec is stable.  So:
-            // time one replay, destroy, re-instantiate, and accept the first exec whose replay is within 2% of the
-            // fastest seen so far and not slower than the eager run; after 5 attempts fall back to eager launches
-            // if the last one is anomalously slow.  Every replay is a real evaluation of the current parameters,
-            // so whichever attempt is accepted leaves the right result behind.  (No device-wide sync happens
-            // between a replay and its destroy here, the safe pattern of retire_exec's note.)
-            float seen_ms = 0.f, ms = 0.f;
-            for (int attempt = 0; attempt < 5; ++attempt) {
-                if (!p->exec) GPMC_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
-                GPMC_HIP(hipEventRecord(p->ev0, p->stream));
-                GPMC_HIP(hipGraphLaunch(p->exec, p->stream));
-                GPMC_HIP(hipEventRecord(p->ev1, p->stream));
-                GPMC_HIP(hipEventSynchronize(p->ev1));
-                GPMC_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
-                p->graph_retries = attempt;
-                const bool ok = attempt > 0 && ms <= 1.02f * seen_ms && ms <= 1.25f * p->eager_ms + 0.05f;
-                if (ok || attempt == 4) break;
-                seen_ms = (attempt == 0 || ms < seen_ms) ? ms : seen_ms;
-                GPMC_HIP(hipGraphExecDestroy(p->exec));
-                p->exec = nullptr;
-            }
-            if (ms > 1.25f * p->eager_ms + 0.05f) {
-                retire_exec(p);
-                p->graph_off = true;
-            }
-            p->graph_checked = true;
-        }
+        rc = p->sched.replay();
+        if (rc) return rc;
     }
     p->evals++;
+    p->slot_busy[slot] = 1;
     double* hres = reinterpret_cast<double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
     GPMC_HIP(hipMemcpyAsync(hres, p->ws + p->L.off_out, 4 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (!p->slot_ev[slot]) GPMC_HIP(hipEventCreateWithFlags(&p->slot_ev[slot], hipEventDisableTiming));
+    GPMC_HIP(hipEventRecord(p->slot_ev[slot], p->stream));
     return 0;
 }
 
-/* diagnostic only (not in gpmc.h): churn graph objects to find which runtime pattern is unsafe.
-   mode 0: instantiate / launch / sync / destroy exec, same captured graph;  mode 1: capture + instantiate / launch /
-   sync / destroy exec + graph;  mode 2: instantiate + launch, keep every exec alive, destroy all at the end;
-   mode 3: as 0 with a device-wide sync before the destroy;  mode 4: as 0 but timed with an event pair recorded
-   around the launch and waited on with hipEventSynchronize (what the plan's graph check used to do);
-   mode 6: as 2 (keep every exec alive, destroy all at the end) with a device-wide sync after every launch;
-   mode 7: as 1 (capture and destroy the graph every iteration too) with a device-wide sync before the destroys;
-   mode 8: as 3, then one more launch + stream sync (no device sync) right before the destroy;
-   mode 9: as 7 with that extra launch + stream sync before the destroys. */
-int gpmc_debug_graph_churn(gpmc_plan* p, int mode, int iters) {
-    GPMC_ARG(p != nullptr && p->have_data && p->stream != nullptr, 1);
-    GPMC_ARG(iters > 0 && iters <= 4096, 3);
-    hipGraph_t g = nullptr;
-    int rc = 0;
-    auto capture = [&](hipGraph_t* out) -> int {
-        GPMC_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
-        int r = plan_enqueue(p, p->stream);
-        hipError_t e = hipStreamEndCapture(p->stream, out);
-        if (r) return r;
-        if (e != hipSuccess) return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        return 0;
-    };
-    if (mode != 1 && mode != 7 && mode != 9 && (rc = capture(&g))) return rc;
-    hipGraphExec_t* keep = (mode == 2 || mode == 6) ? new hipGraphExec_t[iters]() : nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (mode == 4) { GPMC_HIP(hipEventCreate(&e0)); GPMC_HIP(hipEventCreate(&e1)); }
+/* diagnostic only (not in gpmc.h): churn graph objects -- the destroy patterns that aborted in round 1.
+   form 0: the plan's segmented sequence (linear graphs);  form 1: round 1's single fork/join graph (kept so that the
+   runtime defect stays reproducible: on HIP runtime 7.0.51831 form 1 + device_sync aborts, on 7.2.26015 it does not).
+   Per iteration: record, replay, stream sync, optionally hipDeviceSynchronize, destroy every exec. */
+int gpmc_debug_graph_churn(gpmc_plan* p, int form, int device_sync, int iters) {
+    GPMC_ARG(p != nullptr && p->have_data && p->stream != nullptr && p->evals > 0, 1);
+    GPMC_ARG(iters > 0 && iters <= 4096, 4);
+    GPMC_HIP(hipStreamSynchronize(p->stream));
+    (void)p->sched.drop_ops();
+    p->recorded = false;
     for (int i = 0; i < iters; ++i) {
-        hipGraphExec_t x = nullptr;
-        if ((mode == 1 || mode == 7 || mode == 9) && (rc = capture(&g))) return rc;
-        GPMC_HIP(hipGraphInstantiate(&x, g, nullptr, nullptr, 0));
-        if (mode == 4) {
-            float ms = 0.f;
-            GPMC_HIP(hipEventRecord(e0, p->stream));
-            GPMC_HIP(hipGraphLaunch(x, p->stream));
-            GPMC_HIP(hipEventRecord(e1, p->stream));
-            GPMC_HIP(hipEventSynchronize(e1));
-            GPMC_HIP(hipEventElapsedTime(&ms, e0, e1));
-        } else {
-            GPMC_HIP(hipGraphLaunch(x, p->stream));
-            GPMC_HIP(hipStreamSynchronize(p->stream));
-        }
-        if (mode == 3 || mode == 6 || mode == 7 || mode == 8 || mode == 9) GPMC_HIP(hipDeviceSynchronize());
-        if (mode == 8 || mode == 9) {
-            GPMC_HIP(hipGraphLaunch(x, p->stream));
-            GPMC_HIP(hipStreamSynchronize(p->stream));
-        }
-        if (keep) keep[i] = x; else GPMC_HIP(hipGraphExecDestroy(x));
-        if (mode == 1 || mode == 7 || mode == 9) { GPMC_HIP(hipGraphDestroy(g)); g = nullptr; }
+        int rc = p->sched.begin(form ? Sched::FORKJOIN : Sched::SEGMENTS);
+        if (rc) return rc;
+        rc = plan_enqueue(p, p->stream);
+        const int rc2 = p->sched.end();
+        if (rc || rc2) { (void)p->sched.drop_ops(); return rc ? rc : rc2; }
+        rc = p->sched.replay();
+        if (rc) return rc;
+        GPMC_HIP(hipStreamSynchronize(p->stream));
+        if (device_sync) GPMC_HIP(hipDeviceSynchronize());
+        rc = p->sched.drop_ops();
+        if (rc) return rc;
     }
-    if (keep) { for (int i = 0; i < iters; ++i) GPMC_HIP(hipGraphExecDestroy(keep[i])); delete[] keep; }
-    if (g) GPMC_HIP(hipGraphDestroy(g));
-    if (e0) { GPMC_HIP(hipEventDestroy(e0)); GPMC_HIP(hipEventDestroy(e1)); }
+    return 0;
+}
+
+/* diagnostic only: number of ops / graph launches in the plan's recorded sequence (0 before the second evaluation) */
+int gpmc_debug_plan_ops(gpmc_plan* p, int* n_ops, int* n_graphs) {
+    GPMC_ARG(p != nullptr, 1);
+    int g = 0;
+    for (const SeqOp& o : p->sched.ops) g += (o.kind == 0);
+    if (n_ops) *n_ops = (int)p->sched.ops.size();
+    if (n_graphs) *n_graphs = g;
     return 0;
 }
 
@@ -440,7 +379,10 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host) {
     GPMC_ARG(p != nullptr, 1);
     GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 2);
     GPMC_ARG(out_host != nullptr, 3);
-    GPMC_HIP(hipStreamSynchronize(p->stream));
+    if (p->slot_busy[slot]) {                        // wait for THIS slot's evaluation only: later ones keep running
+        GPMC_HIP(hipEventSynchronize(p->slot_ev[slot]));
+        p->slot_busy[slot] = 0;
+    }
     const double* hres = reinterpret_cast<const double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
     for (int i = 0; i < 4; ++i) out_host[i] = hres[i];
     return 0;
@@ -458,9 +400,9 @@ int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld) {
 int gpmc_plan_destroy(gpmc_plan* p) {
     if (!p) return 0;
     (void)hipStreamSynchronize(p->stream);
-    retire_exec(p);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
-    if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
+    if (p->sched.panel) (void)hipStreamSynchronize(p->sched.panel);
+    (void)p->sched.destroy();     // plain destroys of linear graph execs, the events, the panel stream
+    for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
     if (p->host_pin) (void)hipHostFree(p->host_pin);
     delete p;
     return 0;

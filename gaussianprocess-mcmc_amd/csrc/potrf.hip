@@ -34,20 +34,6 @@ namespace gpmc {
 Options g_opt;
 thread_local char g_err[512] = {0};
 
-static Aux g_aux;
-static int g_lds_pad_now = 0;   // extra dynamic LDS for the big-tile GEMM, decided per factorisation
-int aux_get(Aux** out) {
-    if (!g_aux.ready) {
-        int lo = 0, hi = 0;
-        GPMC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        GPMC_HIP(hipStreamCreateWithPriority(&g_aux.panel_stream, hipStreamNonBlocking, hi));
-        for (auto& e : g_aux.ev) GPMC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        g_aux.ready = true;
-    }
-    *out = &g_aux;
-    return 0;
-}
-
 // ======================================================================= diagonal block
 // Factor the 64x64 block at Wd (lower triangle read) in LDS and write L back (strict upper = 0).
 // Column step c applies a[i][j] -= a[i][c] a[j][c] / d_c directly from the unscaled column, so only
@@ -311,7 +297,7 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, int ldcin, T* C, int ldc, int mrows,
                        int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s,
-                       int ktri = 0) {
+                       int ktri = 0, int lds_pad = 0) {
     constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
     constexpr int BK = 128 / (int)sizeof(T);
     if (mrows <= 0 || ncols <= 0) return 0;
@@ -328,7 +314,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
-            if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && g_lds_pad_now == 0 && nblk >= 64) {
+            if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && lds_pad == 0 && nblk >= 64) {
                 // persistent pipelined kernel: one 512-thread workgroup per CU walks the tile list, next C tile
                 // prefetched under the current K loop
                 auto kp = gemm4p_nt_kernel<EPI>;
@@ -344,7 +330,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
-            if (BM == 128 && g_lds_pad_now > 0 && g_opt.gemm_8wave) {
+            if (BM == 128 && lds_pad > 0 && g_opt.gemm_8wave) {
                 // look-ahead phase: one workgroup per CU -> make it 8 waves (2 per SIMD), wave tile 32 x 64
                 auto k8 = gemm4_nt_kernel<4, 2, 8, 4, EPI>;
                 static bool attr8_done = false;
@@ -353,7 +339,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     attr8_done = true;
                 }
-                hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)g_lds_pad_now, s, A, lda, B, ldb, Cin, ldcin,
+                hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)lds_pad, s, A, lda, B, ldb, Cin, ldcin,
                                    C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0, ktri);
                 GPMC_LAUNCH_CHECK();
                 return 0;
@@ -379,7 +365,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr4_done = true;
             }
-            const size_t smem4 = smem + ((BM == 128) ? (size_t)g_lds_pad_now : 0);
+            const size_t smem4 = smem + ((BM == 128) ? (size_t)lds_pad : 0);
             int xmap = 0, nblk4 = nblk;
             if (g_opt.gemm_xcd_map && mt >= 16) {   // super-block order; grid = (#super-blocks rounded to 8) * 64
                 const int SC = (ntc + 7) / 8, SR = (mt + 7) / 8;
@@ -450,7 +436,7 @@ int profile_read(double* out) {   // out: [0] total ms in the kernel, [1] launch
 // C(mrows x ncols region) -= A A_j^T, big (128x128) or small (64x64) tiles by problem size
 template <typename T>
 static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi,
-                           bool latency_bound = false) {
+                           bool latency_bound = false, int lds_pad = 0) {
     // update columns [col_lo, col_hi) of the trailing matrix (rows >= col_lo), K = nbk panel at k0
     const int rows = mp - col_lo;
     const int cols = col_hi - col_lo;
@@ -468,7 +454,7 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
     }
     int rc;
     if (rows > g_opt.small_tile_m && !latency_bound)
-        rc = launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
+        rc = launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s, 0, lds_pad);
     else
         rc = launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
     if (rc) return rc;
@@ -568,7 +554,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
 }
 
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri) {
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri, Sched* sc) {
     GPMC_ARG(W != nullptr, 1);
     GPMC_ARG(np_ > 0 && np_ % GPMC_PAD == 0, 3);
     GPMC_ARG(mp >= np_ && mp % GPMC_PAD == 0, 2);
@@ -577,6 +563,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(scratch != nullptr, 6);
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
     GPMC_ARG(ntri >= 0 && ntri % GPMC_PAD == 0 && ntri <= mp - np_, 8);
+    GPMC_ARG(sc == nullptr || sc->main == s, 9);
     // The last ntri riding rows are upper-trapezoidal on entry (riding row mp - ntri + i is zero left of column i, e.g.
     // a scaled identity, which leaves s L^-T behind).  Row i then stays zero in every column < i, so while the panel
     // ending at column kend is factored or applied only the first kend of those rows can hold anything: the launches
@@ -598,7 +585,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         return 0;
     };
     // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k) for
-    // np_ >= 6144, f64 and f32 alike, outer block by remaining columns (la_nb below)
+    // np_ >= la_min_np, f64 and f32 alike, outer block by remaining columns (la_nb below)
     const bool la = (g_opt.lookahead < 0) ? (np_ >= g_opt.la_min_np && fused) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
     if (NB <= 0) NB = la ? 256 : ((sizeof(T) == 4 && np_ >= 4096) ? g_opt.f32_nb : 128);
@@ -618,7 +605,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // workgroups free whole CUs for the panel kernel at a finer grain; that pays below np_ = 8192 only (6144: 3.95 vs
     // 4.03 ms) -- from 8192 on two GEMM workgroups per CU win (8192: 6.73 vs 6.79, 16384: 33.8 vs 36.2, 32768: 227 vs 253).
     const int la_pad = (np_ >= 8192) ? 0 : 16000;
-    g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? (la ? la_pad : 0) : g_opt.gemm_lds_pad;
+    const int pad_serial = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
+    const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
     // serial schedule from column kstart on (the panel at kstart is factored first), outer block nbs
@@ -629,29 +617,26 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (rc) return rc;
             const int k1 = k0 + nbk;
             if (k1 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_, false, pad_serial);
                 if (rc) return rc;
             }
         }
         return 0;
     };
     if (!la || np_ <= NB) {
-        g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
         int rc = serial_from(0, NB);
         if (rc) return rc;
         return final_flush();
     }
 
     // ---- look-ahead: after panel k, update only the next panel's columns first (on s), then factor
-    // panel k+1 on the high-priority panel stream while the remaining columns are updated on s.
-    Aux* ax;
-    {
-        int rc = aux_get(&ax);
-        if (rc) return rc;
+    // panel k+1 on the high-priority panel stream while the remaining columns are updated on s.  The cross-stream
+    // edges go through the schedule object (eager events, or cuts of the plan's recorded sequence: gpmc_common.h).
+    if (!sc) {
+        sc = eager_sched(s);
+        if (!sc) return fail(-1, "potrf: cannot create the look-ahead stream");
     }
-    hipStream_t ps = ax->panel_stream;
-    int evi = 0;
-    auto next_ev = [&]() { hipEvent_t e = ax->ev[evi]; evi = (evi + 1) % 16; return e; };
+    hipStream_t ps = sc->panel;
     if (g_opt.la_depth == 2) {
         // ---- depth-2 look-ahead.  With c_k = k NB:
         //   panel stream : P_0 | U_1 P_1 | U_2 P_2 | ...   U_{k+1} = columns [c_{k+1}, c_{k+2}) -= panel k (small tiles),
@@ -662,27 +647,30 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // cross-stream hand-over per step leave its critical path.
         hipEvent_t pe_prev, ge_prev = nullptr;
         {
-            hipEvent_t ef = next_ev();   // fork: the panel stream starts behind whatever built the matrix on s
-            GPMC_HIP(hipEventRecord(ef, s));
-            GPMC_HIP(hipStreamWaitEvent(ps, ef, 0));
-            const int nbk = (np_ < NB) ? np_ : NB;
-            int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, ps, pk, lpark21, false);
+            hipEvent_t ef;   // fork: the panel stream starts behind whatever built the matrix on s
+            int rc = sc->edge_record(s, &ef);
             if (rc) return rc;
-            pe_prev = next_ev();
-            GPMC_HIP(hipEventRecord(pe_prev, ps));
+            rc = sc->edge_wait(ps, ef);
+            if (rc) return rc;
+            const int nbk = (np_ < NB) ? np_ : NB;
+            rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, ps, pk, lpark21, false);
+            if (rc) return rc;
+            rc = sc->edge_record(ps, &pe_prev);
+            if (rc) return rc;
         }
         for (int k0 = 0; k0 < np_; k0 += NB) {
             const int nbk = (np_ - k0 < NB) ? np_ - k0 : NB;
             const int k1 = k0 + nbk;
             if (k1 >= np_) {   // panel k was the last one: join
-                GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
+                int rc = sc->edge_wait(s, pe_prev);
+                if (rc) return rc;
                 break;
             }
             if (np_ - k1 < g_opt.la_min_m) {
                 // tail: join, bring the whole remaining matrix up to panel k, continue serially with NB = 128
-                GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
-                g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
-                int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
+                int rc = sc->edge_wait(s, pe_prev);
+                if (rc) return rc;
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_, false, pad_serial);
                 if (rc) return rc;
                 rc = serial_from(k1, 128);
                 if (rc) return rc;
@@ -691,20 +679,24 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             const int nbn = (np_ - k1 < NB) ? np_ - k1 : NB;
             const int k2 = k1 + nbn;
             // panel stream: U_{k+1}, P_{k+1}
-            if (ge_prev) GPMC_HIP(hipStreamWaitEvent(ps, ge_prev, 0));
-            int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, ps, k1, k2, true);
+            int rc = 0;
+            if (ge_prev) rc = sc->edge_wait(ps, ge_prev);
+            if (rc) return rc;
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, ps, k1, k2, true, pad_la);
             if (rc) return rc;
             rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k2), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps, pk, lpark21, true);
             if (rc) return rc;
-            hipEvent_t pe_next = next_ev();
-            GPMC_HIP(hipEventRecord(pe_next, ps));
+            hipEvent_t pe_next;
+            rc = sc->edge_record(ps, &pe_next);
+            if (rc) return rc;
             // main stream: G_k
-            GPMC_HIP(hipStreamWaitEvent(s, pe_prev, 0));
+            rc = sc->edge_wait(s, pe_prev);
+            if (rc) return rc;
             if (k2 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_);
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_, false, pad_la);
                 if (rc) return rc;
-                ge_prev = next_ev();
-                GPMC_HIP(hipEventRecord(ge_prev, s));
+                rc = sc->edge_record(s, &ge_prev);
+                if (rc) return rc;
             }
             pe_prev = pe_next;
         }
@@ -722,8 +714,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (k1 >= np_) break;
         if (np_ - k1 < g_opt.la_min_m) {
             // tail: the GEMM no longer hides the (contention-stretched) panel chain -> serial, NB = 128, 2 WGs/CU
-            g_lds_pad_now = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
-            int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_);
+            int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_, false, pad_serial);
             if (rc) return rc;
             rc = serial_from(k1, 128);
             if (rc) return rc;
@@ -732,30 +723,30 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);  // next panel width
         nb_next = nbn;
         // (1) next panel's columns, on s
-        int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, k1 + nbn, true);
+        int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, k1 + nbn, true, pad_la);
         if (rc) return rc;
-        hipEvent_t e1 = next_ev();
-        GPMC_HIP(hipEventRecord(e1, s));
-        // Enqueue order matters under graph replay: the runtime keeps a node's first-added successor on the same
-        // hardware queue and sends later-added ones across (~11 us per crossing, measured from the kernel trace).
-        // la_order = 1 issues (3) before (2), so the main-stream chain (1) -> (3) -> (1') stays on one queue and
-        // the crossings move to the panel chain, which has slack.
+        hipEvent_t e1, e2;
+        rc = sc->edge_record(s, &e1);
+        if (rc) return rc;
+        // la_order = 1 issues (3) before (2) (enqueue-order experiment, measured slower)
         if (g_opt.la_order == 1 && k1 + nbn < np_) {
-            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_);
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_, false, pad_la);
             if (rc) return rc;
         }
         // (2) factor next panel on ps
-        GPMC_HIP(hipStreamWaitEvent(ps, e1, 0));
+        rc = sc->edge_wait(ps, e1);
+        if (rc) return rc;
         rc = factor_panel<T>(W, ldw, k1, nbn, mp_at(k1 + nbn), info_dev, dinv + (size_t)(k1 / NB_IN) * 1024, lpark, ps, pk, lpark21, true);
         if (rc) return rc;
-        hipEvent_t e2 = next_ev();
-        GPMC_HIP(hipEventRecord(e2, ps));
+        rc = sc->edge_record(ps, &e2);
+        if (rc) return rc;
         // (3) the rest of the trailing matrix, on s, concurrently with (2)
         if (g_opt.la_order != 1 && k1 + nbn < np_) {
-            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_);
+            rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1 + nbn, np_, false, pad_la);
             if (rc) return rc;
         }
-        GPMC_HIP(hipStreamWaitEvent(s, e2, 0));
+        rc = sc->edge_wait(s, e2);
+        if (rc) return rc;
     }
     return final_flush();
 }
@@ -846,8 +837,8 @@ int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStrea
     return 0;
 }
 
-template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int);
-template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int);
+template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int, Sched*);
+template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int, Sched*);
 template int syrk_tri<double>(const double*, int, double, double*, int, int, int, hipStream_t);
 template int syrk_tri<float>(const float*, int, float, float*, int, int, int, hipStream_t);
 template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);

@@ -40,6 +40,7 @@ class LogMarginalPlan(object):
             raise _lib.GpmcError('gpmc_plan_workspace_bytes rejected n=%d d=%d' % (self.n, self.d))
         self.workspace = torch.empty(self._nbytes, dtype=torch.uint8, device=self.X.device)  # caller-owned memory
         self._h = None
+        self._armed = set()
         self._stream, self._h = self._create()
         if tune_stream is None:
             la = _lib.get_option('lookahead')
@@ -71,7 +72,7 @@ class LogMarginalPlan(object):
         return stream, h
 
     def _replay_ms(self, h, reps=3):
-        """warm the plan up (eager evaluation, capture, the C side's own graph check) at neutral parameters
+        """warm the plan up (eager evaluation, then the recording of the launch sequence) at neutral parameters
         [sf2, Sii, ell..] = 1 -- K + I is positive definite and the time does not depend on the values -- then the wall
         time per evaluation of ``reps`` back-to-back replays"""
         import time
@@ -80,12 +81,14 @@ class LogMarginalPlan(object):
         ptr = kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         out = (ctypes.c_double * 4)()
         for i in range(3):
-            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], 0), 'gpmc_plan_logml_async')
-        _lib.check(L.gpmc_plan_result(h, 0, out), 'gpmc_plan_result')
+            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], i), 'gpmc_plan_logml_async')
+        for i in range(3):
+            _lib.check(L.gpmc_plan_result(h, i, out), 'gpmc_plan_result')
         t0 = time.perf_counter()
         for i in range(reps):
-            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], 0), 'gpmc_plan_logml_async')
-        _lib.check(L.gpmc_plan_result(h, 0, out), 'gpmc_plan_result')
+            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], i), 'gpmc_plan_logml_async')
+        for i in range(reps):
+            _lib.check(L.gpmc_plan_result(h, i, out), 'gpmc_plan_result')
         return 1e3 * (time.perf_counter() - t0) / reps
 
     def set_g(self, g):
@@ -102,15 +105,23 @@ class LogMarginalPlan(object):
         return kp
 
     def eval_async(self, hyp, slot=0):
+        """enqueue one evaluation into result slot ``slot`` (0..63); a slot whose evaluation is still in flight cannot be
+        re-armed (GpmcError) until ``result(slot)`` has read it"""
         kp = np.ascontiguousarray(self.kparams(hyp), dtype=np.float64)
         _lib.check(_lib.lib().gpmc_plan_logml_async(self._h, kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                                     kp.shape[0], slot), 'gpmc_plan_logml_async')
+        self._armed.add(slot)
 
     def result(self, slot=0):
-        """(logml, logdet, quad, info) of the evaluation enqueued into ``slot``; synchronises the stream."""
+        """(logml, logdet, quad, info) of the evaluation enqueued into ``slot``; waits for that evaluation only."""
         out = (ctypes.c_double * 4)()
         _lib.check(_lib.lib().gpmc_plan_result(self._h, slot, out), 'gpmc_plan_result')
+        self._armed.discard(slot)
         return float(out[0]), float(out[1]), float(out[2]), int(out[3])
+
+    def drain(self):
+        """read (and so free) every slot that still has an unread evaluation; returns {slot: result}"""
+        return {s: self.result(s) for s in sorted(self._armed)}
 
     def __call__(self, hyp):
         self.eval_async(hyp, 0)

@@ -179,7 +179,8 @@ int gpmc_gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double*
 /* ---- fused plan: one log-marginal evaluation per call -------------------------------------------
  * The metric's unit (a1 + a2 + a3 + a11): for hyper-parameters hyp (host, linear
  * scale: ell[1 or d], sf, sn) build K + S into the plan's workspace, factor it with g riding as an
- * extra row, reduce.  The launch sequence is captured once into a hipGraph per plan and replayed.
+ * extra row, reduce.  The launch sequence is recorded once per plan as linear hipGraphs cut at the cross-stream edges
+ * of the look-ahead (the plan owns its second stream and events) and replayed.
  * All device memory is the caller's: `workspace` of gpmc_plan_workspace_bytes(n, d, elem_size).
  */
 typedef struct gpmc_plan gpmc_plan;
@@ -188,18 +189,21 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
                      size_t workspace_bytes, gpmc_stream_t stream);
 /* X: n x d host or device row-major (copied into the workspace), g: n elements */
 int gpmc_plan_set_data(gpmc_plan* p, const void* X_dev, int ldx, const void* g_dev);
-/* asynchronous: enqueue one evaluation; the result lands in host result slot `slot` (0..63).
+/* asynchronous: enqueue one evaluation; the result lands in host result slot `slot` (0..63).  A slot also owns the
+ * pinned staging of its parameters: re-arming a slot whose evaluation has not been read back with gpmc_plan_result
+ * returns -4 (nothing is enqueued).
  * kparams_host = kernel-ready parameters in gpmc_kbuild's hyp layout, as doubles: [sf^2, S_ii, ell...]
  * (nk = 3 for RBF, 2 + d for ARD) -- the caller forms them from the sampler's (ell, sf, sn) exactly as the
  * reference does: exp(log .) round trips and the S_ii expression of sliceSample.py:184-187. */
 int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int slot);
-/* synchronise the plan's stream and read result slot: out_host[0]=logml, [1]=logdet, [2]=quad, [3]=info */
+/* wait for the evaluation enqueued into `slot` (later evaluations keep running) and read it:
+ * out_host[0]=logml, [1]=logdet, [2]=quad, [3]=info.  Frees the slot. */
 int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
 /* device pointer / geometry of the factored workspace of the last evaluation (for callers that go on
  * to use L): W, mp, np_, ld */
 int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
-/* synchronises the plan's stream and releases the plan.  The workspace and stream passed to gpmc_plan_create must
- * still be valid: retiring the captured launch graph replays the last evaluation once (see plan.hip). */
+/* synchronises the plan's streams and releases the plan (its look-ahead stream, events and recorded launch graphs).
+ * The stream passed to gpmc_plan_create must still be valid; the workspace is not touched. */
 int gpmc_plan_destroy(gpmc_plan* p);
 
 /* instrumentation of the dominant kernel (the trailing SYRK update of gpmc_potrf): between begin and read every

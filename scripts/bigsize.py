@@ -16,7 +16,7 @@ a = plan(hyp)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(3):
     plan.eval_async(hyp, i)
-plan.result(2); torch.cuda.synchronize()
+plan.drain(); torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print('n=%d f64: %.1f ms/eval (%.1f TF/s of N^3/3), logml %.9e' % (n, dt * 1e3, n ** 3 / 3 / dt / 1e12, a), flush=True)
 plan.close()

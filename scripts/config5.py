@@ -23,7 +23,7 @@ for dt, nb, la in cases:
     reps = 6
     for i in range(reps):
         plan.eval_async(hyps[i % 4], i)
-    plan.result(reps - 1); torch.cuda.synchronize()
+    plan.drain(); torch.cuda.synchronize()
     dtm = (time.perf_counter() - t0) / reps
     print('f32_nb=%d lookahead=%d ' % (nb, la) + '%s n=%d d=%d: %.2f ms/eval  %.1f evals/s  %.1f TF/s   logml=%.8g' % (str(dt)[6:], n, d, dtm * 1e3, 1 / dtm, n ** 3 / 3 / dtm / 1e12, v[0]), flush=True)
     plan.close()

@@ -25,6 +25,6 @@ for h in hyps:
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(6):
     plan.eval_async(hyps[i % 2], i)
-plan.result(5); torch.cuda.synchronize()
+plan.drain(); torch.cuda.synchronize()
 print('n=%d %s: %.3f ms/eval' % (n, ' '.join(sys.argv[2:]), (time.perf_counter() - t0) / 6 * 1e3))
 plan.close()

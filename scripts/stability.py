@@ -17,7 +17,7 @@ for trial in range(24):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(8):
             plan.eval_async(hyps[i % 4], i)
-        plan.result(7); torch.cuda.synchronize()
+        plan.drain(); torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / 8 * 1e3)
     print('trial %d: %s ms/eval   stream tuning (a, b) = %s' % (trial, ' '.join('%.2f' % p for p in per), None if plan.tuned is None else '%.2f / %.2f' % plan.tuned), flush=True)
     plan.close()

@@ -207,3 +207,35 @@ def test_cross_valid_fold_fanout_world_size_2_gloo(tmp_path):
     rows = (out / 'llkGap3.csv').read_text().strip().splitlines()
     assert rows[0] == 'gap,0,1,2,3,4,5,6' and rows[1].startswith('3,') and len(rows[1].split(',')) == 8
     assert (out / 'hypGap2.csv').read_text().splitlines()[0] == 'll,sf2,sn'
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must come back as a 2-rank job (round 1 parsed the flag
+    and ignored it).  CPU rehearsal: gloo + the stub plan (GPMC_BENCH_STUB=1: no GPU work, plumbing only)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GPMC_DIST_BACKEND='gloo', GPMC_BENCH_STUB='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--n', '64'], env=env, capture_output=True, timeout=240)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # ONE JSON line, from rank 0
+    doc = json.loads(lines[0])
+    assert doc['n_gpus'] == 2 and doc['steps'] == 3 and doc['scaling'] == 'weak'
+    assert doc['value'] > 0 and abs(doc['value'] - 2 * 3 / (doc['ms_per_step'] * 3e-3)) < 1e-6 * doc['value']
+    assert 'STUB' in doc['data'] and doc['cpu_baseline'] is None
+
+
+def test_bench_under_a_launcher_keeps_working():
+    """the torch.distributed.run form the driver uses for N > 1 must not spawn again"""
+    import json
+    import subprocess
+    env = dict(os.environ, GPMC_DIST_BACKEND='gloo', GPMC_BENCH_STUB='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29611', os.path.join(ROOT, 'bench.py'),
+                          '--gpus', '2', '--steps', '2', '--warmup', '1'], env=env, capture_output=True, timeout=240)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2

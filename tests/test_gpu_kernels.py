@@ -368,8 +368,8 @@ def test_trmv_upper(gp, n):
 
 
 def test_two_live_plans_interleaved(gp):
-    """Two plans alive in one process (different sizes, one of them on the look-ahead schedule) share the library's
-    auxiliary panel stream and event ring; interleaved asynchronous evaluations must still return each plan's own
+    """Two plans alive in one process (different sizes, one of them on the look-ahead schedule; each owns its panel
+    stream, events and recorded sequence): interleaved asynchronous evaluations must return each plan's own
     values, bit for bit equal to what the plan computes alone."""
     core = gp['core']
     xa, ga = _x(6400, 2, 21), np.random.RandomState(22).standard_normal(6400) * 5.
@@ -424,3 +424,71 @@ def test_plan_input_dimension_limits(gp):
     assert abs(got - ref) <= 1e-8 * abs(ref)
     with pytest.raises(gp['gpmc'].GpmcError):
         gp['core'].LogMarginalPlan(rng.uniform(0, 3, (n, 63)), g, 'matern52ard')
+
+
+# ---------------------------------------------------------------------------------- plan lifecycle (round 2)
+def _churn(gp, plan, form, devsync, iters):
+    import ctypes
+    from gpmc import _lib
+    L = _lib.lib()
+    L.gpmc_debug_graph_churn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.gpmc_debug_graph_churn.restype = ctypes.c_int
+    _lib.check(L.gpmc_debug_graph_churn(plan._h, form, devsync, iters), 'gpmc_debug_graph_churn')
+
+
+def test_recorded_sequence_survives_device_sync_then_destroy(gp):
+    """Round 1's abort (VERDICT weak #12): a replayed launch graph destroyed after a device-wide sync.  The plan's
+    recorded sequence is now a list of single-stream graphs, so record / replay / hipDeviceSynchronize / destroy --
+    the exact pattern that killed the process (scripts/graph_stress.py 1 1 ...) -- must simply work, on the look-ahead
+    schedule (n = 4200 -> two streams), and leave the plan usable and bit-identical afterwards."""
+    import ctypes
+    from gpmc import _lib
+    n = 4200
+    x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
+    hyp = [1.0, 10.0, 1.2]
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    before = [plan(hyp) for _ in range(2)]
+    L = _lib.lib()
+    L.gpmc_debug_plan_ops.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    nops, ngr = ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.gpmc_debug_plan_ops(plan._h, ctypes.byref(nops), ctypes.byref(ngr)), 'gpmc_debug_plan_ops')
+    assert ngr.value >= 3 and nops.value > ngr.value       # really cut at cross-stream edges: graphs + event ops
+    _churn(gp, plan, 0, 1, 6)
+    torch.cuda.synchronize()
+    after = plan(hyp)                                        # re-records after the churn dropped the sequence
+    assert after == before[0] == before[1]
+    ref = sds_ref.gp_log_marginal(x, g, hyp)
+    assert abs(after - ref) <= 1e-10 * abs(ref)
+    torch.cuda.synchronize()
+    plan.close()
+
+
+def test_plan_destroy_does_not_touch_the_workspace(gp):
+    """gpmc_plan_destroy used to replay the last evaluation into the caller's workspace before destroying the graph
+    exec; now it must neither write nor need it: poison the workspace after the last result, destroy, compare."""
+    n = 4200
+    x, g = _x(n, 2, 33), np.random.RandomState(34).standard_normal(n) * 5.
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    for _ in range(3):
+        plan([1.0, 10.0, 1.2])
+    torch.cuda.synchronize()
+    plan.workspace.fill_(0x5a)
+    torch.cuda.synchronize()
+    plan.close()
+    torch.cuda.synchronize()
+    assert bool((plan.workspace == 0x5a).all())
+
+
+def test_slot_rearm_in_flight_is_rejected(gp):
+    from gpmc import _lib
+    n = 600
+    x, g = _x(n, 2, 35), np.random.RandomState(36).standard_normal(n)
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    plan.eval_async([1.0, 10.0, 1.2], 5)
+    with pytest.raises(_lib.GpmcError, match='in flight'):
+        plan.eval_async([2.0, 8.0, 1.0], 5)
+    a = plan.result(5)[0]
+    plan.eval_async([2.0, 8.0, 1.0], 5)                      # free again after the read
+    b = plan.result(5)[0]
+    assert a == plan([1.0, 10.0, 1.2]) and b == plan([2.0, 8.0, 1.0])
+    plan.close()
