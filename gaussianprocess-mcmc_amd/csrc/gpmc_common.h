@@ -50,7 +50,9 @@ struct Options {
     int panel_lds_pad = 0;    // extra LDS bytes requested by the 64-column panel kernel beside the GEMM; 16384+ makes it wait
                               // for an empty CU instead of sharing one: 8192 6.58 vs 6.41 ms, 16384 33.6 vs 32.8 -> stays 0
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
-    int use_graph = 1;        // capture the plan's launch sequence into a hipGraph
+    int use_graph = 1;        // record the plan's launch sequence once and replay it
+    int replay_form = 1;      // 1: one fork/join hipGraph (6.6 ms at N=8192); 0: linear graphs cut at the cross-stream edges
+                              // (7.9 ms; no exec spans two streams) -- see Sched below
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
     int f32_nb = 256;         // outer block of the serial f32 factorisation for np_ >= 4096
     int gemm_lds_pad = -1;    // extra dynamic LDS bytes requested by the big-tile f64 GEMM under look-ahead; -1 = auto: 16000
@@ -149,21 +151,32 @@ int trmv_upper(const T* W, int n, int ldw, const T* x, const T* y0, double alpha
 // between them.  Three ways to run the same host code (potrf() only ever calls edge_record / edge_wait and launches
 // kernels on sc.main / sc.panel):
 //   EAGER     edges are hipEventRecord / hipStreamWaitEvent, kernels run as they are launched.
-//   SEGMENTS  (the plan's replay form) both streams are in stream capture; every edge CUTS the capture of the stream it
-//             touches, so the sequence becomes an op list  [linear graph | record | wait | linear graph | ...]  that
-//             replay() re-issues in order.  Every graph is single-stream: no exec ever owns internal branch streams.
-//             Why: on the HIP runtime bundled with the torch wheel (7.0.51831) destroying a FORK/JOIN exec after a
-//             device-wide sync is a use-after-free inside the runtime's signal-handler thread
-//             (amd::roc::VirtualGPU::updateCommandsState -> ReferenceCountedObject::release -> free(); same binary on
-//             runtime 7.2.26015: clean; scripts/graph_repro*.sh, profiles/r02_graph_abort_isolation.txt), the
-//             instantiation of such an exec sometimes serialises its branches, and the runtime picks the branch's
-//             hardware queue.  Linear graphs tied by our own events on our own two streams have none of the three.
-//   FORKJOIN  (diagnostic only: gpmc_debug_graph_churn) round 1's form, one graph with the panel stream forked in.
+//   FORKJOIN  (the plan's default replay form) main is in stream capture and the edges pull the panel stream into the
+//             same capture: ONE graph whose cross-stream dependencies the runtime resolves itself -- measured free on
+//             the device timeline (scripts/graph_launch_cost.hip: a 240-kernel two-stream ping-pong replays in
+//             1798 us as one fork/join graph, 1794 us as a single-stream graph).
+//   SEGMENTS  both streams are in stream capture and every edge CUTS the capture of the stream it touches: an op list
+//             [linear graph | record | wait | linear graph | ...] that replay() re-issues in order.  No exec spans two
+//             streams, so none of the fork/join hazards below exist -- but every eager edge costs ~13-16 us and every
+//             small graph launch ~5 us on the device timeline (same script: 3478 us for the ping-pong), +1.2 ms per
+//             evaluation at N = 8192 (7.9 vs 6.6 ms).  Kept as the deterministic fallback (replay_form = 0).
+// Fork/join hazard on the HIP runtime bundled with the torch wheel (7.0.51831), root-caused in round 2
+// (profiles/r02_graph_abort_isolation.txt): destroying a fork/join exec after a device-wide synchronisation is a
+// use-after-free INSIDE THE RUNTIME -- its signal-handler thread (amd::roc::HsaAmdSignalHandler ->
+// VirtualGPU::updateCommandsState -> ReferenceCountedObject::release -> free()) still owns the marker command the
+// device sync put on the exec's internal branch stream when hipGraphExecDestroy frees it.  The identical libgpmc
+// binary, capture and destroy sequence is clean on runtime 7.2.26015 (with or without torch in the process), and the
+// 7.0 runtime aborts the same way from a plain C++ harness, so neither torch nor this library's capture pattern is an
+// ingredient.  drop_ops() therefore retires a fork/join exec on runtimes < 7.2 by launching it once more with EVERY
+// node disabled (nothing executes, no memory is touched) and synchronising the stream: that flushes the handler
+// thread's pending work on the internal streams, after which the destroy is safe (480 cycles in round 1 with a live
+// replay, gpmc_debug_graph_churn with the disabled one).
 struct SeqOp {
     int kind;              // 0 graph launch, 1 event record, 2 stream wait
     int on_panel;          // which stream: 0 main, 1 panel
     hipGraphExec_t exec;
     hipEvent_t ev;
+    hipGraph_t graph;      // fork/join op only: the template, kept for its node handles (retirement)
 };
 struct Sched {
     enum Mode { EAGER = 0, SEGMENTS = 1, FORKJOIN = 2 };

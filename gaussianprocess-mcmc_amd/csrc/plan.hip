@@ -51,6 +51,9 @@ struct gpmc_plan {
     size_t hyp_slot_bytes;
     gpmc::Sched sched;    // the plan's own panel stream, events and recorded launch sequence
     bool recorded;
+    hipEvent_t ev0, ev1;  // timing of the eager first evaluation and of the first replay (see record_sequence)
+    float eager_ms, replay_ms;
+    int record_attempts, recorded_form;
     int evals;
     bool have_data;
     unsigned char slot_busy[64];   // PLAN_SLOTS: 1 while an evaluation using the slot's staging / result is in flight
@@ -79,6 +82,38 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
 
 static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
     return p->es == 8 ? plan_enqueue_body<double>(p, s) : plan_enqueue_body<float>(p, s);
+}
+
+// Record the plan's launch sequence and run it once, timed (the run IS the evaluation the caller asked for).
+// A fork/join exec's branch is mapped onto a hardware queue by the runtime at instantiation; measured on both HIP
+// runtimes here, about one instantiation in ten lands the branch on the main stream's queue and the look-ahead
+// serialises (10 ms instead of 6.4 ms at N = 8192; each exec is stable for its lifetime).  The recorded sequence must
+// not be slower than launching the same kernels eagerly, so a replay more than 10 % over the eager first evaluation
+// is dropped (through Sched::drop_ops, the one way an exec leaves) and recorded again, at most 3 times; then the
+// linear-graph form, which has no runtime-chosen queue, is recorded instead.
+static int record_sequence(gpmc_plan* p) {
+    const int max_forkjoin = g_opt.replay_form ? 3 : 0;
+    for (int attempt = 0; attempt <= max_forkjoin; ++attempt) {
+        const int form = attempt < max_forkjoin ? Sched::FORKJOIN : Sched::SEGMENTS;
+        int rc = p->sched.begin(form);
+        if (rc) return rc;
+        rc = plan_enqueue(p, p->stream);
+        const int rc2 = p->sched.end();
+        if (rc || rc2) { (void)p->sched.drop_ops(); return rc ? rc : rc2; }
+        GPMC_HIP(hipEventRecord(p->ev0, p->stream));
+        rc = p->sched.replay();
+        if (rc) return rc;
+        GPMC_HIP(hipEventRecord(p->ev1, p->stream));
+        GPMC_HIP(hipEventSynchronize(p->ev1));
+        GPMC_HIP(hipEventElapsedTime(&p->replay_ms, p->ev0, p->ev1));
+        p->record_attempts = attempt + 1;
+        p->recorded_form = form;
+        if (form == Sched::SEGMENTS || p->replay_ms <= 1.10f * p->eager_ms + 0.02f) break;
+        rc = p->sched.drop_ops();
+        if (rc) return rc;
+    }
+    p->recorded = true;
+    return 0;
 }
 
 }  // namespace gpmc
@@ -116,6 +151,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "f32_nb")) g_opt.f32_nb = value;
     else if (!strcmp(name, "gemm_small_bk32")) g_opt.gemm_small_bk32 = value;
     else if (!strcmp(name, "gemm_persistent")) g_opt.gemm_persistent = value;
+    else if (!strcmp(name, "replay_form")) g_opt.replay_form = value ? 1 : 0;
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -143,6 +179,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "f32_nb")) return g_opt.f32_nb;
     if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;
     if (!strcmp(name, "gemm_persistent")) return g_opt.gemm_persistent;
+    if (!strcmp(name, "replay_form")) return g_opt.replay_form;
     return -1;
 }
 
@@ -263,6 +300,7 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     p->ws = reinterpret_cast<char*>(workspace);
     p->stream = S_(stream);
     p->recorded = false; p->evals = 0; p->have_data = false;
+    p->ev0 = p->ev1 = nullptr; p->eager_ms = p->replay_ms = 0.f; p->record_attempts = 0; p->recorded_form = -1;
     memset(p->slot_busy, 0, sizeof(p->slot_busy));
     memset(p->slot_ev, 0, sizeof(p->slot_ev));
     {   // the plan's own look-ahead stream and one event per cross-stream edge of its schedule (2 per 128 columns
@@ -315,19 +353,25 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     const bool graph_ok = g_opt.use_graph && p->stream != nullptr;   // the NULL stream cannot be captured
     if (!graph_ok || p->evals == 0) {
         // eager launches; the first evaluation always (it sets the kernels' attributes, which a capture would record)
+        // and timed: the yardstick for the recorded sequence below
+        const bool timeit = graph_ok && p->evals == 0;
+        if (timeit) {
+            if (!p->ev0) { GPMC_HIP(hipEventCreate(&p->ev0)); GPMC_HIP(hipEventCreate(&p->ev1)); }
+            GPMC_HIP(hipEventRecord(p->ev0, p->stream));
+        }
         p->sched.mode = Sched::EAGER;
         rc = plan_enqueue(p, p->stream);
         if (rc) return rc;
-    } else {
-        if (!p->recorded) {
-            rc = p->sched.begin(Sched::SEGMENTS);
-            if (rc) return rc;
-            rc = plan_enqueue(p, p->stream);
-            const int rc2 = p->sched.end();
-            if (rc || rc2) { (void)p->sched.drop_ops(); return rc ? rc : rc2; }
-            p->recorded = true;
+        if (timeit) {
+            GPMC_HIP(hipEventRecord(p->ev1, p->stream));
+            GPMC_HIP(hipEventSynchronize(p->ev1));
+            GPMC_HIP(hipEventElapsedTime(&p->eager_ms, p->ev0, p->ev1));
         }
+    } else if (p->recorded) {
         rc = p->sched.replay();
+        if (rc) return rc;
+    } else {
+        rc = record_sequence(p);      // records AND replays once (a real evaluation of the current parameters)
         if (rc) return rc;
     }
     p->evals++;
@@ -366,6 +410,11 @@ int gpmc_debug_graph_churn(gpmc_plan* p, int form, int device_sync, int iters) {
 }
 
 /* diagnostic only: number of ops / graph launches in the plan's recorded sequence (0 before the second evaluation) */
+int gpmc_debug_plan_record_info(gpmc_plan* p, double* out4) {   /* eager ms, replay ms, attempts, form */
+    GPMC_ARG(p != nullptr && out4 != nullptr, 1);
+    out4[0] = p->eager_ms; out4[1] = p->replay_ms; out4[2] = p->record_attempts; out4[3] = p->recorded_form;
+    return 0;
+}
 int gpmc_debug_plan_ops(gpmc_plan* p, int* n_ops, int* n_graphs) {
     GPMC_ARG(p != nullptr, 1);
     int g = 0;
@@ -403,6 +452,7 @@ int gpmc_plan_destroy(gpmc_plan* p) {
     if (p->sched.panel) (void)hipStreamSynchronize(p->sched.panel);
     (void)p->sched.destroy();     // plain destroys of linear graph execs, the events, the panel stream
     for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
+    if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     if (p->host_pin) (void)hipHostFree(p->host_pin);
     delete p;
     return 0;

@@ -42,7 +42,7 @@ int Sched::cut(hipStream_t s) {
                 (void)hipGraphDestroy(g);
                 return fail((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
             }
-            ops.push_back(SeqOp{0, is_panel ? 1 : 0, x, nullptr});
+            ops.push_back(SeqOp{0, is_panel ? 1 : 0, x, nullptr, nullptr});
         }
         GPMC_HIP(hipGraphDestroy(g));
     }
@@ -57,7 +57,7 @@ int Sched::edge_record(hipStream_t s, hipEvent_t* out) {
         hipEvent_t e = events[ev_next++];
         int rc = cut(s);
         if (rc) return rc;
-        ops.push_back(SeqOp{1, s == panel ? 1 : 0, nullptr, e});
+        ops.push_back(SeqOp{1, s == panel ? 1 : 0, nullptr, e, nullptr});
         *out = e;
         return 0;
     }
@@ -72,7 +72,7 @@ int Sched::edge_wait(hipStream_t s, hipEvent_t e) {
     if (mode == SEGMENTS) {
         int rc = cut(s);
         if (rc) return rc;
-        ops.push_back(SeqOp{2, s == panel ? 1 : 0, nullptr, e});
+        ops.push_back(SeqOp{2, s == panel ? 1 : 0, nullptr, e, nullptr});
         return 0;
     }
     GPMC_HIP(hipStreamWaitEvent(s, e, 0));
@@ -91,6 +91,7 @@ int Sched::begin(int mode_) {
 
 int Sched::end() {
     if (mode == EAGER) return 0;
+    const bool forkjoin = (mode == FORKJOIN);
     int rc = 0;
     // close what is still open; a failed launch sequence must not leave a stream in capture mode
     for (int k = 0; k < 2; ++k) {
@@ -103,13 +104,17 @@ int Sched::end() {
         if (e != hipSuccess) { if (!rc) rc = fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e)); continue; }
         size_t nodes = 0;
         e = hipGraphGetNodes(g, nullptr, &nodes);
+        bool keep_graph = false;
         if (e == hipSuccess && nodes > 0) {
             hipGraphExec_t x = nullptr;
             e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
-            if (e == hipSuccess) ops.push_back(SeqOp{0, k, x, nullptr});
+            if (e == hipSuccess) {
+                ops.push_back(SeqOp{0, k, x, nullptr, forkjoin ? g : nullptr});
+                keep_graph = forkjoin;
+            }
         }
         if (e != hipSuccess && !rc) rc = fail((int)e, "closing capture: %s", hipGetErrorString(e));
-        (void)hipGraphDestroy(g);
+        if (!keep_graph) (void)hipGraphDestroy(g);
     }
     mode = EAGER;
     ev_next = 0;
@@ -126,13 +131,34 @@ int Sched::replay() {
     return 0;
 }
 
+// HIP runtimes before 7.2 need a fork/join exec flushed before it is destroyed (gpmc_common.h, Sched)
+static bool forkjoin_needs_flush() {
+    static int need = -1;
+    if (need < 0) {
+        int v = 0;
+        need = (hipRuntimeGetVersion(&v) != hipSuccess || v < 70200000) ? 1 : 0;
+    }
+    return need == 1;
+}
+
 int Sched::drop_ops() {
     int rc = 0;
-    for (SeqOp& o : ops)
-        if (o.kind == 0 && o.exec) {
-            hipError_t e = hipGraphExecDestroy(o.exec);
-            if (e != hipSuccess && !rc) rc = fail((int)e, "hipGraphExecDestroy: %s", hipGetErrorString(e));
+    for (SeqOp& o : ops) {
+        if (o.kind != 0 || !o.exec) continue;
+        if (o.graph && forkjoin_needs_flush()) {
+            // one launch with every node disabled: nothing runs, nothing is read or written
+            size_t n = 0;
+            bool ok = (hipGraphGetNodes(o.graph, nullptr, &n) == hipSuccess);
+            std::vector<hipGraphNode_t> nodes(n);
+            ok = ok && (n == 0 || hipGraphGetNodes(o.graph, nodes.data(), &n) == hipSuccess);
+            for (size_t i = 0; ok && i < n; ++i) ok = (hipGraphNodeSetEnabled(o.exec, nodes[i], 0) == hipSuccess);
+            if (ok && hipGraphLaunch(o.exec, main) == hipSuccess) (void)hipStreamSynchronize(main);
+            else if (!rc) rc = fail(-1, "Sched::drop_ops: could not flush a fork/join exec before destroying it");
         }
+        hipError_t e = hipGraphExecDestroy(o.exec);
+        if (e != hipSuccess && !rc) rc = fail((int)e, "hipGraphExecDestroy: %s", hipGetErrorString(e));
+        if (o.graph) (void)hipGraphDestroy(o.graph);
+    }
     ops.clear();
     return rc;
 }

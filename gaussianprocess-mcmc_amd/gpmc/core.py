@@ -16,14 +16,11 @@ _ES = {torch.float64: 8, torch.float32: 4}
 
 
 class LogMarginalPlan(object):
-    """``tune_stream``: None = auto.  On the look-ahead schedule the captured launch sequence has a branch whose
-    hardware queue the graph runtime picks; when it coincides with the queue of the plan's own stream the overlap
-    partly serialises (7.05 instead of 6.74 ms at N = 8192, for every 4th stream of torch's pool -- DESIGN.md, graph
-    lifecycle).  Which pool stream a plan gets depends on what else the process created before (e.g. RCCL under
-    torch.distributed), so for look-ahead sizes the constructor times a few replays on two consecutive pool streams
-    and keeps the faster (a one-off of ~0.1 s at N = 8192; the plan is then warm: captured, validated)."""
+    """One (kernel, X, g) problem bound to device memory it owns; ``plan(hyp)`` / ``eval_async`` + ``result`` evaluate
+    the log-marginal at fresh hyper-parameters.  The first evaluation launches eagerly, the second records the launch
+    sequence (and validates it against the eager time, csrc/plan.hip ``record_sequence``), later ones replay it."""
 
-    def __init__(self, X, g, kernel='rbf', dtype=torch.float64, tune_stream=None):
+    def __init__(self, X, g, kernel='rbf', dtype=torch.float64):
         ops.require_gpu()
         self.kernel = kernel
         self.dtype = dtype
@@ -41,55 +38,23 @@ class LogMarginalPlan(object):
         self.workspace = torch.empty(self._nbytes, dtype=torch.uint8, device=self.X.device)  # caller-owned memory
         self._h = None
         self._armed = set()
-        self._stream, self._h = self._create()
-        if tune_stream is None:
-            la = _lib.get_option('lookahead')
-            tune_stream = bool(_lib.get_option('use_graph')) and la != 0 and \
-                (la > 0 or ops.pad(self.n) >= _lib.get_option('la_min_np'))
-        self.tuned = None
-        if tune_stream:
-            t_a = self._replay_ms(self._h)
-            stream_b, h_b = self._create()                        # the next stream of the pool: another hardware queue
-            t_b = self._replay_ms(h_b)
-            self.tuned = (t_a, t_b)
-            if t_b < 0.98 * t_a:
-                L.gpmc_plan_destroy(self._h)
-                self._stream, self._h = stream_b, h_b
-            else:
-                L.gpmc_plan_destroy(h_b)
-
-    def _create(self):
-        """a plan handle on a stream of its own (the legacy NULL stream torch starts on cannot be graph-captured);
-        all candidates share the one workspace, so only one of them may run at a time"""
-        L = _lib.lib()
-        stream = torch.cuda.Stream(device=self.X.device)
-        stream.wait_stream(torch.cuda.current_stream())
+        # a stream of its own: the legacy NULL stream torch starts on cannot be graph-captured
+        self._stream = torch.cuda.Stream(device=self.X.device)
+        self._stream.wait_stream(torch.cuda.current_stream())
         h = ctypes.c_void_p()
         _lib.check(L.gpmc_plan_create(ctypes.byref(h), ops.KERNELS[self.kernel], self.n, self.d, _ES[self.dtype],
-                                      self.workspace.data_ptr(), self._nbytes, stream.cuda_stream), 'gpmc_plan_create')
+                                      self.workspace.data_ptr(), self._nbytes, self._stream.cuda_stream), 'gpmc_plan_create')
+        self._h = h
         _lib.check(L.gpmc_plan_set_data(h, self.X.data_ptr(), self.X.stride(0), self.g.data_ptr()),
                    'gpmc_plan_set_data')
-        return stream, h
 
-    def _replay_ms(self, h, reps=3):
-        """warm the plan up (eager evaluation, then the recording of the launch sequence) at neutral parameters
-        [sf2, Sii, ell..] = 1 -- K + I is positive definite and the time does not depend on the values -- then the wall
-        time per evaluation of ``reps`` back-to-back replays"""
-        import time
+    def record_info(self):
+        """(eager ms, first replay ms, recording attempts, form: 2 fork/join / 1 linear segments / -1 none yet)"""
         L = _lib.lib()
-        kp = np.ones(2 + (1 if self.kernel == 'rbf' else self.d), dtype=np.float64)
-        ptr = kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        L.gpmc_debug_plan_record_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         out = (ctypes.c_double * 4)()
-        for i in range(3):
-            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], i), 'gpmc_plan_logml_async')
-        for i in range(3):
-            _lib.check(L.gpmc_plan_result(h, i, out), 'gpmc_plan_result')
-        t0 = time.perf_counter()
-        for i in range(reps):
-            _lib.check(L.gpmc_plan_logml_async(h, ptr, kp.shape[0], i), 'gpmc_plan_logml_async')
-        for i in range(reps):
-            _lib.check(L.gpmc_plan_result(h, i, out), 'gpmc_plan_result')
-        return 1e3 * (time.perf_counter() - t0) / reps
+        _lib.check(L.gpmc_debug_plan_record_info(self._h, out), 'gpmc_debug_plan_record_info')
+        return float(out[0]), float(out[1]), int(out[2]), int(out[3])
 
     def set_g(self, g):
         self.g = ops.to_dev(g, self.dtype).reshape(-1)
@@ -156,7 +121,7 @@ class LogMarginalPlan(object):
 
 def log_marginal(X, g, hyp, kernel='rbf', dtype=torch.float64):
     """One-shot convenience: log N(g; 0, K(hyp) + S).  Build a LogMarginalPlan for repeated calls."""
-    plan = LogMarginalPlan(X, g, kernel, dtype, tune_stream=False)
+    plan = LogMarginalPlan(X, g, kernel, dtype)
     try:
         return plan(hyp)
     finally:

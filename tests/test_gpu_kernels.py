@@ -436,31 +436,43 @@ def _churn(gp, plan, form, devsync, iters):
     _lib.check(L.gpmc_debug_graph_churn(plan._h, form, devsync, iters), 'gpmc_debug_graph_churn')
 
 
-def test_recorded_sequence_survives_device_sync_then_destroy(gp):
-    """Round 1's abort (VERDICT weak #12): a replayed launch graph destroyed after a device-wide sync.  The plan's
-    recorded sequence is now a list of single-stream graphs, so record / replay / hipDeviceSynchronize / destroy --
-    the exact pattern that killed the process (scripts/graph_stress.py 1 1 ...) -- must simply work, on the look-ahead
-    schedule (n = 4200 -> two streams), and leave the plan usable and bit-identical afterwards."""
+@pytest.mark.parametrize('form', [1, 0])
+def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
+    """Round 1's abort (VERDICT weak #12): a replayed launch graph destroyed after a device-wide sync, on the look-ahead
+    schedule (n = 4200 -> two streams).  Root cause (profiles/r02_graph_abort_isolation.txt): a use-after-free inside
+    HIP runtime 7.0.51831 -- the one torch bundles, i.e. the one this test runs on -- when a FORK/JOIN exec is destroyed
+    after hipDeviceSynchronize.  form 1 = the default fork/join replay, retired through a launch with every node
+    disabled; form 0 = linear graphs cut at the cross-stream edges, plain destroys.  Both must survive record / replay /
+    hipDeviceSynchronize / destroy cycles, leave the workspace alone while retiring, and the plan usable and
+    bit-identical afterwards."""
     import ctypes
     from gpmc import _lib
+    gpmc = gp['gpmc']
     n = 4200
     x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
     hyp = [1.0, 10.0, 1.2]
-    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
-    before = [plan(hyp) for _ in range(2)]
-    L = _lib.lib()
-    L.gpmc_debug_plan_ops.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
-    nops, ngr = ctypes.c_int(), ctypes.c_int()
-    _lib.check(L.gpmc_debug_plan_ops(plan._h, ctypes.byref(nops), ctypes.byref(ngr)), 'gpmc_debug_plan_ops')
-    assert ngr.value >= 3 and nops.value > ngr.value       # really cut at cross-stream edges: graphs + event ops
-    _churn(gp, plan, 0, 1, 6)
-    torch.cuda.synchronize()
-    after = plan(hyp)                                        # re-records after the churn dropped the sequence
-    assert after == before[0] == before[1]
-    ref = sds_ref.gp_log_marginal(x, g, hyp)
-    assert abs(after - ref) <= 1e-10 * abs(ref)
-    torch.cuda.synchronize()
-    plan.close()
+    try:
+        gpmc.set_option('replay_form', form)
+        plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+        before = [plan(hyp) for _ in range(2)]
+        L = _lib.lib()
+        L.gpmc_debug_plan_ops.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        nops, ngr = ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.gpmc_debug_plan_ops(plan._h, ctypes.byref(nops), ctypes.byref(ngr)), 'gpmc_debug_plan_ops')
+        if form == 0:
+            assert ngr.value >= 3 and nops.value > ngr.value    # really cut at cross-stream edges: graphs + event ops
+        else:
+            assert ngr.value == 1 and nops.value == 1
+        _churn(gp, plan, form, 1, 8)
+        torch.cuda.synchronize()
+        after = plan(hyp)                                        # re-records after the churn dropped the sequence
+        assert after == before[0] == before[1]
+        ref = sds_ref.gp_log_marginal(x, g, hyp)
+        assert abs(after - ref) <= 1e-10 * abs(ref)
+        torch.cuda.synchronize()                                 # device-wide sync right before the destroy
+        plan.close()
+    finally:
+        gpmc.set_option('replay_form', 1)
 
 
 def test_plan_destroy_does_not_touch_the_workspace(gp):
