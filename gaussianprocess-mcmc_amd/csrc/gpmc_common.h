@@ -38,9 +38,11 @@ struct Options {
     int outer_nb = 0;         // outer block of the right-looking Cholesky (multiple of 128); 0 = auto: 128 serial (f32: f32_nb
                               // from np_ 4096), under look-ahead 256 / 384 / 512 by remaining columns
     int lookahead = -1;       // factor panel k+1 on a second stream while the rest of update k runs; -1 = auto: np_ >= la_min_np
-    int la_min_np = 4096;     // auto look-ahead from this padded size on (4096: 2.25 -> 2.10 ms, 5120: 3.16 -> 2.88; 3072: no gain)
+    int la_min_np = 4096;     // auto look-ahead from this padded size on (4096: 2.25 -> 2.10 ms, 5120: 3.16 -> 2.88; 3072: no gain);
+                              // problems the tile-DAG launch (tail.h) takes whole never look ahead
     int la_nb128_m = 0;       // under look-ahead: outer block 128 once fewer columns than this remain (0 = never)
-    int la_min_m = 2048;      // under look-ahead: switch to the serial NB = 128 schedule once fewer columns than this remain
+    int la_min_m = 2048;      // under look-ahead, where the tile-DAG launch is not available (f32, trapezoidal riding rows):
+                              // switch to the serial NB = 128 chain once fewer columns than this remain
                               // (2048 vs 3072 with the 128-column panel launch: 8192 6.41 vs 6.51 ms, 6144 3.83 vs 3.88)
     int la_depth = 1;         // 1: next-panel-column update on the main stream; 2: on the panel stream (measured slower)
     int la_order = 0;         // look-ahead enqueue order per step: 0 = panel work first, 1 = big GEMM first (measured slower)
@@ -50,6 +52,8 @@ struct Options {
     int panel_lds_pad = 0;    // extra LDS bytes requested by the 64-column panel kernel beside the GEMM; 16384+ makes it wait
                               // for an empty CU instead of sharing one: 8192 6.58 vs 6.41 ms, 16384 33.6 vs 32.8 -> stays 0
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
+    int tail_m = 4096;        // f64: the last <= tail_m columns (a multiple of 64, <= 4096; 0 = never) are factored by the
+                              // one-launch tile-DAG kernel (tail.h) instead of the serial NB = 128 launch chain
     int use_graph = 1;        // record the plan's launch sequence once and replay it
     int replay_form = 1;      // 1: one fork/join hipGraph (6.6 ms at N=8192); 0: linear graphs cut at the cross-stream edges
                               // (7.9 ms; no exec spans two streams) -- see Sched below
@@ -114,6 +118,11 @@ __device__ inline typename Mfma<T>::acc_t acc_zero() {
 }
 
 constexpr int NB_IN = 64;  // inner (diagonal-block) size of the Cholesky
+
+// device scratch of potrf(): 16x16 inverse tiles (three-kernel panel path) | parked diagonal factors | parked L21
+// blocks | sync words of the tail kernel
+size_t potrf_scratch_bytes(int np_);
+extern unsigned long long* g_tail_dbg;   // diagnostic stamp buffer of the tail kernel (nullptr in production)
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -35,7 +35,7 @@ static PlanLayout plan_layout(int n, int d, int es) {
     L.off_hyp = take((size_t)(2 + PLAN_MAXD) * es);
     L.off_out = take(4 * sizeof(double));
     L.off_info = take(sizeof(int));
-    L.off_scratch = take((size_t)(L.np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double));
+    L.off_scratch = take(potrf_scratch_bytes(L.np_));
     L.total = o;
     return L;
 }
@@ -125,7 +125,7 @@ extern "C" {
 int gpmc_version(void) { return GPMC_VERSION; }
 const char* gpmc_last_error(void) { return g_err; }
 int gpmc_pad(int n) { return round_up(n, GPMC_PAD); }
-size_t gpmc_potrf_scratch_bytes(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
+size_t gpmc_potrf_scratch_bytes(int np_) { return potrf_scratch_bytes(np_); }
 
 int gpmc_set_option(const char* name, int value) {
     if (!name) return fail(-1, "gpmc_set_option: null name");
@@ -152,6 +152,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_small_bk32")) g_opt.gemm_small_bk32 = value;
     else if (!strcmp(name, "gemm_persistent")) g_opt.gemm_persistent = value;
     else if (!strcmp(name, "replay_form")) g_opt.replay_form = value ? 1 : 0;
+    else if (!strcmp(name, "tail_m")) { if (value < 0 || value > 4096 || value % 64) return fail(-2, "tail_m must be a multiple of 64 in [0, 4096]"); g_opt.tail_m = value; }
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -180,6 +181,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;
     if (!strcmp(name, "gemm_persistent")) return g_opt.gemm_persistent;
     if (!strcmp(name, "replay_form")) return g_opt.replay_form;
+    if (!strcmp(name, "tail_m")) return g_opt.tail_m;
     return -1;
 }
 
@@ -199,6 +201,9 @@ int gpmc_debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info
     double* lpark = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + (size_t)(np_ / NB_IN + 1) * 1024 * sizeof(double));
     return debug_panel_stamps(W, ld, mp, k0, c0, info_dev, lpark, dbg_dev, reinterpret_cast<hipStream_t>(stream));
 }
+/* diagnostic only (not in gpmc.h): eager launches of the tail kernel write 16 s_memtime stamps per tile column into
+   dbg_dev (>= 16 * 64 u64) until this is called again with NULL */
+int gpmc_debug_tail_stamps(unsigned long long* dbg_dev) { gpmc::g_tail_dbg = dbg_dev; return 0; }
 int gpmc_profile_begin(void) { return profile_begin(); }
 int gpmc_profile_read(double* out3) {
     if (!out3) return fail(-1, "gpmc_profile_read: null out");

@@ -28,11 +28,16 @@
 #include "panel_pair.h"
 #include "gemm4.h"
 #include "gemm4p.h"
+#include "tail.h"
 
 namespace gpmc {
 
 Options g_opt;
 thread_local char g_err[512] = {0};
+
+unsigned long long* g_tail_dbg = nullptr;    // diagnostic only (gpmc_debug_tail_stamps): stamp buffer of the next launches
+static size_t potrf_scratch_base(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
+size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + (size_t)TAIL_SYNC_WORDS * sizeof(unsigned); }
 
 // ======================================================================= diagonal block
 // Factor the 64x64 block at Wd (lower triangle read) in LDS and write L back (strict upper = 0).
@@ -576,6 +581,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     Parked pk;
     auto final_flush = [&]() -> int {
         if (!fused) return 0;
+        if (g_opt.panel_impl == 1 && pk.d0 < 0 && pk.d1 < 0 && pk.l21 < 0) return 0;   // nothing parked
         if (g_opt.panel_impl == 1) {   // whatever the last launch parked: one or two diagonal factors and L21
             hipLaunchKernelGGL((panel_flush3_kernel<T>), dim3(3), dim3(256), 0, s, W, ldw, lpark, lpark21, pk.d0, pk.d1, pk.l21);
         } else {
@@ -586,7 +592,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     };
     // schedule: serial with NB = 128 for small problems; look-ahead (panel k+1 beside the rest of update k) for
     // np_ >= la_min_np, f64 and f32 alike, outer block by remaining columns (la_nb below)
-    const bool la = (g_opt.lookahead < 0) ? (np_ >= g_opt.la_min_np && fused) : (g_opt.lookahead != 0);
+    bool la = (g_opt.lookahead < 0) ? (np_ >= g_opt.la_min_np && fused) : (g_opt.lookahead != 0);
     int NB = g_opt.outer_nb;
     if (NB <= 0) NB = la ? 256 : ((sizeof(T) == 4 && np_ >= 4096) ? g_opt.f32_nb : 128);
     if (NB < 128 || NB % 128) NB = 256;
@@ -609,9 +615,36 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
+    // the last columns as one tile-DAG launch (tail.h): f64, no trapezoidal riding rows
+    const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && ntri == 0 && fused && g_opt.panel_impl == 1;
+    auto use_tail = [&](int k0) {
+        return tail_ok && np_ - k0 <= g_opt.tail_m && (np_ - k0) / NB_IN <= TAIL_MAXT && (mp - k0) / NB_IN <= TAIL_MAXR;
+    };
+    auto tail_from = [&](int k0) -> int {
+        int rc = final_flush();     // whatever the last panel launch parked must be in W before tiles are read
+        if (rc) return rc;
+        pk = Parked();
+        unsigned* sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + potrf_scratch_base(np_));
+        const int Tt = (np_ - k0) / NB_IN, Rt = (mp - k0) / NB_IN;
+        GPMC_HIP(hipMemsetAsync(sync, 0, (size_t)(4 + Tt * TAIL_MAXR) * sizeof(unsigned), s));
+        static bool attr_done = false;
+        if (!attr_done) {
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(tail_kernel, dim3(tail_grid(Tt, Rt)), dim3(256), sizeof(TailShared), s,
+                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, sync, info_dev, g_tail_dbg);
+        GPMC_LAUNCH_CHECK();
+        return 0;
+    };
+    if (g_opt.lookahead < 0 && use_tail(0)) la = false;      // the whole problem is one tile-DAG launch
+    // look-ahead hands over to the tail once the tile-DAG launch can take the rest (else: once < la_min_m columns remain)
+    auto hand_over = [&](int k1) { return tail_ok ? use_tail(k1) : (np_ - k1 < g_opt.la_min_m); };
     // serial schedule from column kstart on (the panel at kstart is factored first), outer block nbs
     auto serial_from = [&](int kstart, int nbs) -> int {
         for (int k0 = kstart; k0 < np_; k0 += nbs) {
+            if (use_tail(k0)) return tail_from(k0);
             const int nbk = (np_ - k0 < nbs) ? np_ - k0 : nbs;
             int rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s, pk, lpark21, false);
             if (rc) return rc;
@@ -666,7 +699,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
                 break;
             }
-            if (np_ - k1 < g_opt.la_min_m) {
+            if (hand_over(k1)) {
                 // tail: join, bring the whole remaining matrix up to panel k, continue serially with NB = 128
                 int rc = sc->edge_wait(s, pe_prev);
                 if (rc) return rc;
@@ -712,7 +745,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     for (int k0 = 0, nb_next = 0; k0 < np_; k0 += nbk, nbk = nb_next) {
         const int k1 = k0 + nbk;
         if (k1 >= np_) break;
-        if (np_ - k1 < g_opt.la_min_m) {
+        if (hand_over(k1)) {
             // tail: the GEMM no longer hides the (contention-stretched) panel chain -> serial, NB = 128, 2 WGs/CU
             int rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k1, np_, false, pad_serial);
             if (rc) return rc;

@@ -1,0 +1,302 @@
+// tail.h -- the last columns of the factorisation (and every problem that small) as a tile DAG in ONE launch.
+//
+// The serial tail of the blocked schedule is a chain of ~100 short launches (per 128 columns: two panel launches of
+// 18-23 us and a trailing update of 15-27 us; 1.0 ms for the last 2048 columns at N = 8192, all 0.92 ms of N = 2048):
+// every launch ends with a drained chip and starts with loads of what the previous one just stored.
+// Here the trailing trapezoid (R x T tiles of 64 x 64; R >= T block rows, riding rows included) is factored by one
+// workgroup PER TILE, left-looking:
+//     workgroup of (i,l), i > l :  X = A_il;  for c < l:  X -= L_ic L_lc^T  as soon as both are published;
+//                                  then  L_il = X L_ll^-T  once L_ll is published;  publish.
+//     workgroup of column l     :  owns the PAIR (l,l-1), (l,l): accumulates both, solves (l,l-1) against L_{l-1,l-1},
+//                                  applies it to (l,l) straight from LDS, factors, publishes both -- the two tiles
+//                                  between F(l-1) and F(l) on the critical path never change hands.
+// The tile lives in registers for the workgroup's whole life (16 doubles per thread; diagonal tiles in the slab
+// layout of diag_mp.h, off-diagonal ones transposed as the TRSM wants them -- both are MFMA accumulator layouts, so a
+// tile is never converted) and its FINAL value is written once.
+// * Deadlock freedom without co-residency: blocks are numbered column by column (the pair first), so a workgroup only
+//   ever waits for workgroups with a LOWER block index -- tiles of earlier columns, or its own column's pair.  Blocks
+//   are dispatched in index order, so whatever a resident workgroup waits for is resident or finished; the lowest
+//   unfinished block never waits.  Any grid size, any number of CUs, and other kernels (or another instance of this
+//   one) may share the chip.  Every spin is bounded all the same: a workgroup that gives up raises the abort word,
+//   every other spin sees it within 256 polls, all leave and *info becomes GPMC_TAIL_TIMEOUT -- the grid always drains.
+// * Publishing = writing the tile to its place in W with write-through (sc1) stores, every storing wave draining its
+//   stores, a workgroup barrier, then ONE lane's agent-scope flag store; consumers poll the flag (one lane, relaxed
+//   sc1 loads, s_sleep between polls), pass a workgroup barrier and read the tile with sc1 loads -- the "8-byte agent
+//   atomics on both sides" form of the CDNA4 guide (MI355X_MICROARCH.md, inter-workgroup visibility, row 1 of the
+//   measured hand-off table).  flag[c][i] = 1 once tile (i,c) is in W.  The flags are zeroed by a memset node in
+//   front of every launch (they are polled from the first instruction on).
+#pragma once
+#include "panel_fused.h"
+
+namespace gpmc {
+
+constexpr int TAIL_MAXT = 64;                   // block columns
+constexpr int TAIL_MAXR = 132;                  // block rows (flag row stride)
+constexpr int TAIL_SYNC_WORDS = 4 + TAIL_MAXT * TAIL_MAXR;   // [0] abort word (16-byte slot), then flag[col][row]
+constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // polls before giving up (~1 s)
+constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
+
+struct TailShared {
+    double Ld[64][MP_LD];     // A operand of an update; the diagonal factor (Lout) during FACTOR / TRSM
+    double Ls[64][MP_LD];     // B operand of an update; staging of a tile on its way in / out
+    union {
+        double Praw[64][MP_PLD];
+        double Linv[16][4][4];
+    };
+    double rsd[64];
+    int fail;
+    int ok;
+};
+static_assert(2 * sizeof(TailShared) <= 160 * 1024, "two tile workgroups per CU");
+
+typedef unsigned long long tail_u64;
+
+__device__ inline unsigned tail_ld32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 64 x 64 tile W -> LDS [row][col] with sc1 loads (bytes another workgroup published in this launch)
+__device__ inline void tail_tile_in(double (*dst)[MP_LD], const double* __restrict__ src, int ld, int tid) {
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        const tail_u64 u = __hip_atomic_load(reinterpret_cast<const tail_u64*>(src + (size_t)(e >> 6) * ld + (e & 63)),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[t] = __longlong_as_double((long long)u);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        dst[e >> 6][e & 63] = v[t];
+    }
+}
+
+// LDS [row][col] -> W with write-through stores; tail_drain() + barrier + the flag store follow
+__device__ inline void tail_tile_out(double* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int e = tid + 256 * t;
+        __hip_atomic_store(reinterpret_cast<tail_u64*>(dst + (size_t)(e >> 6) * ld + (e & 63)),
+                           (tail_u64)__double_as_longlong(src[e >> 6][e & 63]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
+__device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsigned* abortw, TailShared& sh, int tid) {
+    if (tid == 0) {
+        int ok = 1;
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned a = tail_ld32(f1), b = tail_ld32(f2);
+            if (a != 0u && b != 0u) break;
+            if ((spins & 255u) == 255u && tail_ld32(abortw) != 0u) { ok = 0; break; }
+            if (spins > TAIL_SPIN_LIMIT) {
+                __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sh.ok = ok;
+    }
+    __syncthreads();
+    const bool ok = sh.ok != 0;
+    __syncthreads();      // sh.ok may be rewritten by the next wait
+    return ok;
+}
+
+// host + device: blocks of tile column l = 1 (the pair) + the off-diagonal tiles below it that no pair owns
+__host__ __device__ inline int tail_first_row(int l, int T) { return (l + 1 < T) ? l + 2 : l + 1; }
+__host__ __device__ inline int tail_col_blocks(int l, int T, int R) {
+    const int n = R - tail_first_row(l, T);
+    return 1 + (n > 0 ? n : 0);
+}
+inline int tail_grid(int T, int R) {
+    int n = 0;
+    for (int l = 0; l < T; ++l) n += tail_col_blocks(l, T, R);
+    return n;
+}
+
+__global__ void __launch_bounds__(256, 2)
+tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __restrict__ sync, int* __restrict__ info,
+            unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) char tail_smem[];
+    TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
+    double (*Lout)[MP_LD] = sh.Ld;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int i = lane >> 4, c = lane & 15, ia = lane & 3;
+    unsigned* const abortw = sync;
+    auto flag = [&](int col, int row) { return sync + 4 + col * TAIL_MAXR + row; };
+    double* const W0 = W + (size_t)k0 * ld + k0;                  // tile (0,0)
+    auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
+
+    // ---------------- which tile(s): column-major block order, the pair first in its column
+    int tl = 0, ti;
+    {
+        int q = blockIdx.x;
+        for (;; ++tl) {
+            const int n = tail_col_blocks(tl, T, R);
+            if (q < n) break;
+            q -= n;
+        }
+        ti = (q == 0) ? tl : tail_first_row(tl, T) + q - 1;
+    }
+    const bool pair = (ti == tl);                 // owns (tl,tl) and, for tl >= 1, (tl, tl-1)
+    if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
+    // diagnostic (dbg != nullptr only from gpmc_debug_tail_stamps): s_memtime stamps of the pair workgroups
+#define TAIL_STAMP(k)                                                                  \
+    do {                                                                               \
+        if (dbg != nullptr && pair && tid == 0) dbg[16 * tl + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+    TAIL_STAMP(0);
+
+    // ---------------- tiles into registers
+    double D[4][4];     // (tl,tl), slab layout: lane (i, c) of D[m][h] = element [4 (w + 4 m) + i][16 h + c]
+    double X[16];       // off-diagonal tile, transposed: lane (i, c) of X[g] = element [16 w + c][4 g + i]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            D[m][h] = (pair && h <= m) ? tile(tl, tl)[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
+    const int xi = pair ? tl : ti, xl = pair ? tl - 1 : tl;       // the off-diagonal tile (xl < 0: none)
+    if (xl >= 0) {
+        const double* src = tile(xi, xl);
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int row = e >> 5, c2 = (e & 31) * 2;
+            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = *reinterpret_cast<const d2_t*>(&src[(size_t)row * ld + c2]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) X[g] = (xl >= 0) ? sh.Ls[16 * w + c][4 * g + i] : 0.0;
+    __syncthreads();
+
+    bool alive = true;
+    // ---------------- left-looking accumulation over the published columns
+    for (int col = 0; col < xl && alive; ++col) {
+        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid);
+        if (!alive) break;
+        tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
+        tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
+        __syncthreads();
+#pragma unroll 2
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int ko = 8 * k8 + 2 * i;
+            const d2_t bT = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);
+#pragma unroll
+            for (int gb = 0; gb < 16; gb += 8) {
+                d2_t aT[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) aT[g] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (gb + g) + ia][ko]);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        X[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aT[g][e2], bT[e2], X[gb + g], 0, 0, 0);
+            }
+            if (pair) {     // (tl,tl) -= L_{tl,col} L_{tl,col}^T, rows of L_{tl,col} in Ls
+                d2_t bD[4], aD[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][ko]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][ko]);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int h = 0; h <= m; ++h)
+                            D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aD[m][e2], bD[h][e2], D[m][h], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
+    TAIL_STAMP(1);
+    if (alive && xl >= 0) {
+        alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid);
+        TAIL_STAMP(2);
+        if (alive) {
+            tail_tile_in(Lout, tile(xl, xl), ld, tid);
+            __syncthreads();
+            TAIL_STAMP(3);
+            if (tid < 16) {
+                const int o = 4 * tid;
+                const double l10 = Lout[o + 1][o];
+                const double l20 = Lout[o + 2][o], l21 = Lout[o + 2][o + 1];
+                const double l30 = Lout[o + 3][o], l31 = Lout[o + 3][o + 1], l32 = Lout[o + 3][o + 2];
+                const double i00 = 1.0 / Lout[o][o], i11 = 1.0 / Lout[o + 1][o + 1], i22 = 1.0 / Lout[o + 2][o + 2],
+                             i33 = 1.0 / Lout[o + 3][o + 3];
+                const double i10 = -(l10 * i00) * i11;
+                const double i21 = -(l21 * i11) * i22;
+                const double i32 = -(l32 * i22) * i33;
+                const double i20 = -(l20 * i00 + l21 * i10) * i22;
+                const double i31 = -(l31 * i11 + l32 * i21) * i33;
+                const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
+                double(*V)[4] = sh.Linv[tid];
+                V[0][0] = i00; V[0][1] = 0.0; V[0][2] = 0.0; V[0][3] = 0.0;
+                V[1][0] = i10; V[1][1] = i11; V[1][2] = 0.0; V[1][3] = 0.0;
+                V[2][0] = i20; V[2][1] = i21; V[2][2] = i22; V[2][3] = 0.0;
+                V[3][0] = i30; V[3][1] = i31; V[3][2] = i32; V[3][3] = i33;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const double av = sh.Linv[p][ia][i];
+                const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, X[p], 0.0, 0, 0, 0);
+                X[p] = Y;
+#pragma unroll
+                for (int g = p + 1; g < 16; ++g) {
+                    const double al = -Lout[4 * g + ia][4 * p + i];
+                    X[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, X[g], 0, 0, 0);
+                }
+            }
+            TAIL_STAMP(4);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = X[g];
+            __syncthreads();
+            tail_tile_out(tile(xi, xl), ld, sh.Ls, tid);       // stores in flight ...
+            if (pair) {
+                // ... while (tl,tl) takes the update by its own column tl-1 straight from LDS
+#pragma unroll 2
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int ko = 8 * k8 + 2 * i;
+                    d2_t bD[4], aD[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][ko]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][ko]);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int h = 0; h <= m; ++h)
+                                D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aD[m][e2], bD[h][e2], D[m][h], 0, 0, 0);
+                }
+            }
+            TAIL_STAMP(5);
+            tail_drain();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag(xl, xi), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            TAIL_STAMP(6);
+        }
+    }
+
+    // ---------------- the diagonal tile: factor, publish
+    if (alive && pair) {
+        mp_factor64(D, Lout, sh.Praw, &sh.fail, sh.rsd, tid, k0 + 64 * tl);    // opens and closes with a barrier
+        TAIL_STAMP(7);
+        if (tid == 0 && sh.fail != 0) atomicCAS(info, 0, sh.fail);
+        tail_tile_out(tile(tl, tl), ld, Lout, tid);
+        tail_drain();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag(tl, tl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TAIL_STAMP(8);
+    }
+    if (!alive && tid == 0) atomicCAS(info, 0, GPMC_TAIL_TIMEOUT);
+}
+
+}  // namespace gpmc

@@ -104,6 +104,20 @@ def check(rc, what=''):
         raise GpmcError('%s failed (rc=%d): %s' % (what or 'libgpmc call', rc, msg.decode() if msg else '?'))
 
 
+TAIL_TIMEOUT = -1001     # *info when the tile-DAG kernel (csrc/tail.h) gave up waiting: an error, not "not positive definite"
+
+
+def check_info(info):
+    """pass a factorisation's LAPACK-style info through; raise if it is the tile-DAG kernel's timeout code (its
+    bounded spins ran out: the GPU was held by other work for about a second, or blocks were not dispatched in
+    index order)"""
+    info = int(info)
+    if info == TAIL_TIMEOUT:
+        raise GpmcError('tile-DAG factorisation kernel timed out waiting for another workgroup (info=%d); '
+                        'set_option("tail_m", 0) selects the launch-chain schedule' % info)
+    return info
+
+
 def set_option(name, value):
     check(lib().gpmc_set_option(name.encode(), int(value)), 'gpmc_set_option')
 

@@ -82,7 +82,7 @@ class LogMarginalPlan(object):
         out = (ctypes.c_double * 4)()
         _lib.check(_lib.lib().gpmc_plan_result(self._h, slot, out), 'gpmc_plan_result')
         self._armed.discard(slot)
-        return float(out[0]), float(out[1]), float(out[2]), int(out[3])
+        return float(out[0]), float(out[1]), float(out[2]), _lib.check_info(out[3])
 
     def drain(self):
         """read (and so free) every slot that still has an unread evaluation; returns {slot: result}"""

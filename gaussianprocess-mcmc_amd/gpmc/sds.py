@@ -23,7 +23,7 @@ decision (tests/test_gpu_sds.py); the reference itself spends ~11.3 N^3 flops he
 import numpy as np
 import torch
 
-from . import covK, ops
+from . import _lib, covK, ops
 
 R_JITTER = 1e-11          # sliceSample.py:205
 
@@ -136,7 +136,7 @@ class SDSWorkspace(object):
         self._make_R(g)
         self._chol_R(f, need_eta, 0.0)
         res = self.out.cpu().numpy()                             # the one sync of the happy path (scalars)
-        infoA, infoR = int(res[3]), int(self.infoR.item())
+        infoA, infoR = _lib.check_info(res[3]), _lib.check_info(self.infoR.item())
         if infoA != 0:
             diag_mean = float(self.kp0[0]) + self.Sii            # diag(K + S) is constant and positive
             jitter = diag_mean * 1e-9
@@ -145,7 +145,7 @@ class SDSWorkspace(object):
                 self._make_R(g)
                 self._chol_R(f, need_eta, 0.0)
                 res = self.out.cpu().numpy()
-                infoA, infoR = int(res[3]), int(self.infoR.item())
+                infoA, infoR = _lib.check_info(res[3]), _lib.check_info(self.infoR.item())
                 if infoA == 0:
                     break
                 jitter *= 10.
@@ -164,7 +164,7 @@ class SDSWorkspace(object):
                 if t:
                     self.WR[:self.np_].copy_(self.R0)
                 self._chol_R(f, need_eta, jitter)
-                if int(self.infoR.item()) == 0:
+                if _lib.check_info(self.infoR.item()) == 0:
                     break
                 jitter *= 10.
             else:
@@ -219,7 +219,7 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     scratch = ops.potrf_scratch(np_, dev)
     ops.potrf_tri(WA, mpA, np_, np_, info, scratch)
-    if int(info.item()) != 0:
+    if _lib.check_info(info.item()) != 0:
         raise np.linalg.LinAlgError('K + S not positive definite (pivot %d)' % int(info.item()))
     L = ops.unpack_lower(WA, np_, n)
     WR = torch.zeros((np_ + ops.PAD, np_), dtype=dt, device=dev)
@@ -228,7 +228,7 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     m = torch.empty(n, dtype=dt, device=dev)
     ops.trmv_upper(rows, n, WA[np_], g, -1.0, m)
     ops.potrf(WR, np_ + ops.PAD, np_, info, scratch)
-    if int(info.item()) != 0:
+    if _lib.check_info(info.item()) != 0:
         raise np.linalg.LinAlgError('R not positive definite (pivot %d)' % int(info.item()))
     C = ops.unpack_lower(WR, np_, n)
     return g, KS, m, C, L

@@ -8,7 +8,7 @@ schedule the reference pins (requirements.txt:10): on a non-positive pivot requi
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class FactorWorkspace(object):
@@ -35,7 +35,7 @@ class FactorWorkspace(object):
         ops.potrf(self.W, self.mp, self.np_, self.info, self.scratch)
 
     def info_host(self):
-        return int(self.info.item())
+        return _lib.check_info(self.info.item())
 
 
 def jitchol(A, maxtries=5, workspace=None):
