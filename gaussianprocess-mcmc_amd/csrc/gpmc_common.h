@@ -54,6 +54,11 @@ struct Options {
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
     int tail_m = 4096;        // f64: the last <= tail_m columns (a multiple of 64, <= 4096; 0 = never) are factored by the
                               // one-launch tile-DAG kernel (tail.h) instead of the serial NB = 128 launch chain
+    int tail_workers = 448;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
+    int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width
+                              // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
+    int la_dag = 1;           // f64 look-ahead: factor every outer panel with one tile-DAG launch (potrf.hip), 0: round 1's
+                              // next-panel update + per-64/128-column panel launches
     int use_graph = 1;        // record the plan's launch sequence once and replay it
     int replay_form = 1;      // 1: one fork/join hipGraph (6.6 ms at N=8192); 0: linear graphs cut at the cross-stream edges
                               // (7.9 ms; no exec spans two streams) -- see Sched below

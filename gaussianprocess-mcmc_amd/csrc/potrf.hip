@@ -37,7 +37,7 @@ thread_local char g_err[512] = {0};
 
 unsigned long long* g_tail_dbg = nullptr;    // diagnostic only (gpmc_debug_tail_stamps): stamp buffer of the next launches
 static size_t potrf_scratch_base(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
-size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + (size_t)TAIL_SYNC_WORDS * sizeof(unsigned); }
+size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + TAIL_SYNC_BYTES; }
 
 // ======================================================================= diagonal block
 // Factor the 64x64 block at Wd (lower triangle read) in LDS and write L back (strict upper = 0).
@@ -618,25 +618,43 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // the last columns as one tile-DAG launch (tail.h): f64, no trapezoidal riding rows
     const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && ntri == 0 && fused && g_opt.panel_impl == 1;
     auto use_tail = [&](int k0) {
-        return tail_ok && np_ - k0 <= g_opt.tail_m && (np_ - k0) / NB_IN <= TAIL_MAXT && (mp - k0) / NB_IN <= TAIL_MAXR;
+        return tail_ok && np_ - k0 <= g_opt.tail_m && (np_ - k0) / NB_IN <= TAIL_MAXT &&
+               tail_sync_words((np_ - k0) / NB_IN, (mp - k0) / NB_IN) * sizeof(unsigned) <= TAIL_SYNC_BYTES;
     };
-    auto tail_from = [&](int k0) -> int {
-        int rc = final_flush();     // whatever the last panel launch parked must be in W before tiles are read
-        if (rc) return rc;
-        pk = Parked();
-        unsigned* sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + potrf_scratch_base(np_));
-        const int Tt = (np_ - k0) / NB_IN, Rt = (mp - k0) / NB_IN;
-        GPMC_HIP(hipMemsetAsync(sync, 0, (size_t)(4 + Tt * TAIL_MAXR) * sizeof(unsigned), s));
+    unsigned* const dag_sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + potrf_scratch_base(np_));
+    // one tile-DAG launch on stream st: block columns [k0, k0 + 64 Tt) of rows k0 .. mp_rows, accumulating first over
+    // the Hh finished block columns to their left.  sync_next = word offset of this launch's sync region; with
+    // sync_zeroed the whole range was zeroed by ONE memset at the start of the factorisation (see tail.h), else the
+    // region is zeroed right here.
+    size_t sync_next = 0;
+    bool sync_zeroed = false;
+    auto dag_launch = [&](int k0, int Tt, int mp_rows, int Hh, hipStream_t st, int workers) -> int {
+        const int Rt = (mp_rows - k0) / NB_IN;
+        const size_t words = tail_sync_words(Tt, Rt);
+        if (!sync_zeroed) sync_next = 0;
+        if ((sync_next + words) * sizeof(unsigned) > TAIL_SYNC_BYTES) return fail(-1, "potrf: sync region overflow");
+        unsigned* sync = dag_sync + sync_next;
+        if (!sync_zeroed) GPMC_HIP(hipMemsetAsync(sync, 0, words * sizeof(unsigned), st));
+        sync_next += words;
         static bool attr_done = false;
         if (!attr_done) {
             GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
             attr_done = true;
         }
-        hipLaunchKernelGGL(tail_kernel, dim3(tail_grid(Tt, Rt)), dim3(256), sizeof(TailShared), s,
-                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, sync, info_dev, g_tail_dbg);
+        // grid = the Tt pairs + workers for the off-diagonal tiles: at most `workers` of them
+        const int ntl = tail_tiles(Tt, Rt);
+        const int grid = Tt + (ntl < workers ? ntl : workers);
+        hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), sizeof(TailShared), st,
+                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, sync, info_dev, g_tail_dbg);
         GPMC_LAUNCH_CHECK();
         return 0;
+    };
+    auto tail_from = [&](int k0) -> int {
+        int rc = final_flush();     // whatever the last panel launch parked must be in W before tiles are read
+        if (rc) return rc;
+        pk = Parked();
+        return dag_launch(k0, (np_ - k0) / NB_IN, mp, 0, s, g_opt.tail_workers);
     };
     if (g_opt.lookahead < 0 && use_tail(0)) la = false;      // the whole problem is one tile-DAG launch
     // look-ahead hands over to the tail once the tile-DAG launch can take the rest (else: once < la_min_m columns remain)
@@ -670,6 +688,74 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (!sc) return fail(-1, "potrf: cannot create the look-ahead stream");
     }
     hipStream_t ps = sc->panel;
+    if (tail_ok && g_opt.la_dag) {
+        // ---- look-ahead with tile-DAG panels.  With c_k the panel starts:
+        //   panel stream : D_0 | D_1 | D_2 | ...   D_{k+1} = ONE tile-DAG launch that factors panel k+1 after accumulating
+        //                                          panel k's update of those columns as left-looking history (no separate
+        //                                          next-panel update, no per-64-column launches waiting for CU slots)
+        //   main stream  : G_0 | G_1 | G_2 | ...   G_k = columns [c_{k+2}, np_) -= panel k (big tiles), back to back
+        // G_k waits for D_k; D_{k+1} waits for G_{k-1} (which brought its columns up to panel k-1).  The hand-over tail is
+        // one more tile-DAG launch with panel k as history.
+        hipEvent_t pe, ge = nullptr;
+        int nbk = la_nb(np_);
+        if (nbk > np_) nbk = np_;
+        {   // sync words of every launch of this schedule, zeroed once, here, on s before the fork
+            size_t total = 0;
+            for (int k0 = 0, nb = nbk;;) {
+                total += tail_sync_words(nb / NB_IN, (mp - k0) / NB_IN);
+                const int k1 = k0 + nb;
+                if (k1 >= np_) break;
+                if (hand_over(k1)) { total += tail_sync_words((np_ - k1) / NB_IN, (mp - k1) / NB_IN); break; }
+                nb = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
+                k0 = k1;
+            }
+            if (total * sizeof(unsigned) <= TAIL_SYNC_BYTES) {
+                GPMC_HIP(hipMemsetAsync(dag_sync, 0, total * sizeof(unsigned), s));
+                sync_zeroed = true;
+            }
+        }
+        {
+            hipEvent_t ef;
+            int rc = sc->edge_record(s, &ef);
+            if (rc) return rc;
+            rc = sc->edge_wait(ps, ef);
+            if (rc) return rc;
+            rc = dag_launch(0, nbk / NB_IN, mp, 0, ps, g_opt.tail_workers);
+            if (rc) return rc;
+            rc = sc->edge_record(ps, &pe);
+            if (rc) return rc;
+        }
+        for (int k0 = 0;;) {
+            const int k1 = k0 + nbk;
+            int rc = 0;
+            if (k1 >= np_) return sc->edge_wait(s, pe);
+            if (hand_over(k1)) {
+                rc = sc->edge_wait(s, pe);
+                if (rc) return rc;
+                return dag_launch(k1, (np_ - k1) / NB_IN, mp, nbk / NB_IN, s, g_opt.tail_workers);
+            }
+            const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
+            const int k2 = k1 + nbn;
+            if (ge) rc = sc->edge_wait(ps, ge);
+            if (rc) return rc;
+            rc = dag_launch(k1, nbn / NB_IN, mp, nbk / NB_IN, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2);
+            if (rc) return rc;
+            hipEvent_t pe_next;
+            rc = sc->edge_record(ps, &pe_next);
+            if (rc) return rc;
+            rc = sc->edge_wait(s, pe);
+            if (rc) return rc;
+            if (k2 < np_) {
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k2, np_, false, pad_la);
+                if (rc) return rc;
+                rc = sc->edge_record(s, &ge);
+                if (rc) return rc;
+            }
+            pe = pe_next;
+            k0 = k1;
+            nbk = nbn;
+        }
+    }
     if (g_opt.la_depth == 2) {
         // ---- depth-2 look-ahead.  With c_k = k NB:
         //   panel stream : P_0 | U_1 P_1 | U_2 P_2 | ...   U_{k+1} = columns [c_{k+1}, c_{k+2}) -= panel k (small tiles),

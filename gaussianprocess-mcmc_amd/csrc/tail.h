@@ -3,36 +3,45 @@
 // The serial tail of the blocked schedule is a chain of ~100 short launches (per 128 columns: two panel launches of
 // 18-23 us and a trailing update of 15-27 us; 1.0 ms for the last 2048 columns at N = 8192, all 0.92 ms of N = 2048):
 // every launch ends with a drained chip and starts with loads of what the previous one just stored.
-// Here the trailing trapezoid (R x T tiles of 64 x 64; R >= T block rows, riding rows included) is factored by one
-// workgroup PER TILE, left-looking:
-//     workgroup of (i,l), i > l :  X = A_il;  for c < l:  X -= L_ic L_lc^T  as soon as both are published;
+// Here the trailing trapezoid (R x T tiles of 64 x 64; R >= T block rows, riding rows included) is factored tile by
+// tile, left-looking, one workgroup working on one tile at a time:
+//     tile (i,l), i > l         :  X = A_il;  for c < l:  X -= L_ic L_lc^T  as soon as both are published;
 //                                  then  L_il = X L_ll^-T  once L_ll is published;  publish.
-//     workgroup of column l     :  owns the PAIR (l,l-1), (l,l): accumulates both, solves (l,l-1) against L_{l-1,l-1},
+//     pair of column l          :  owns the PAIR (l,l-1), (l,l): accumulates both, solves (l,l-1) against L_{l-1,l-1},
 //                                  applies it to (l,l) straight from LDS, factors, publishes both -- the two tiles
 //                                  between F(l-1) and F(l) on the critical path never change hands.
 // The tile lives in registers for the workgroup's whole life (16 doubles per thread; diagonal tiles in the slab
 // layout of diag_mp.h, off-diagonal ones transposed as the TRSM wants them -- both are MFMA accumulator layouts, so a
 // tile is never converted) and its FINAL value is written once.
-// * Deadlock freedom without co-residency: blocks are numbered column by column (the pair first), so a workgroup only
-//   ever waits for workgroups with a LOWER block index -- tiles of earlier columns, or its own column's pair.  Blocks
-//   are dispatched in index order, so whatever a resident workgroup waits for is resident or finished; the lowest
-//   unfinished block never waits.  Any grid size, any number of CUs, and other kernels (or another instance of this
-//   one) may share the chip.  Every spin is bounded all the same: a workgroup that gives up raises the abort word,
-//   every other spin sees it within 256 polls, all leave and *info becomes GPMC_TAIL_TIMEOUT -- the grid always drains.
+// * Workgroups 0 .. T-1 are the pairs, one each, resident from the start: the critical chain never waits for a free
+//   worker.  Workgroups T .. grid-1 are WORKERS: each draws tickets (one agent-scope atomic add) and processes the
+//   off-diagonal tiles in column-major ticket order, so the number of CU slots the launch holds is the grid size the
+//   host picks, not the number of tiles -- beside the trailing GEMM of the look-ahead a launch with one workgroup
+//   per tile parks hundreds of waiting workgroups on slots the GEMM needs.
+// * Deadlock freedom without co-residency of the whole grid: a tile only waits for pairs (workgroups 0 .. T-1) and
+//   for tiles with LOWER tickets (earlier columns), which are held by resident workers or finished; a pair waits for
+//   tiles of earlier columns.  Blocks are dispatched in index order, so as soon as T + 1 workgroups are resident the
+//   lowest unfinished ticket always has everything it needs or is itself being worked on.  Other kernels (or another
+//   instance of this one) may share the chip.  Every spin is bounded all the same: a workgroup that gives up raises
+//   the abort word, every other spin sees it within 256 polls, all leave and *info becomes GPMC_TAIL_TIMEOUT -- the
+//   grid always drains.
 // * Publishing = writing the tile to its place in W with write-through (sc1) stores, every storing wave draining its
 //   stores, a workgroup barrier, then ONE lane's agent-scope flag store; consumers poll the flag (one lane, relaxed
 //   sc1 loads, s_sleep between polls), pass a workgroup barrier and read the tile with sc1 loads -- the "8-byte agent
 //   atomics on both sides" form of the CDNA4 guide (MI355X_MICROARCH.md, inter-workgroup visibility, row 1 of the
-//   measured hand-off table).  flag[c][i] = 1 once tile (i,c) is in W.  The flags are zeroed by a memset node in
-//   front of every launch (they are polled from the first instruction on).
+//   measured hand-off table).  flag[c][i] = 1 once tile (i,c) is in W.  The flags are polled from the first
+//   instruction on, so they are zeroed by a memset node: every launch of a factorisation has its own sync region and
+//   ONE memset in front of the whole factorisation zeroes them all (a memset in front of each launch delays it by
+//   5-10 us, enough for a concurrently launched GEMM to take every CU slot first).
 #pragma once
 #include "panel_fused.h"
 
 namespace gpmc {
 
-constexpr int TAIL_MAXT = 64;                   // block columns
-constexpr int TAIL_MAXR = 132;                  // block rows (flag row stride)
-constexpr int TAIL_SYNC_WORDS = 4 + TAIL_MAXT * TAIL_MAXR;   // [0] abort word (16-byte slot), then flag[col][row]
+constexpr int TAIL_MAXT = 64;                   // block columns of one launch
+// sync words of one launch: [0] abort word (16-byte slot), then flag[col][row], row stride R
+__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R; }
+constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // polls before giving up (~1 s)
 constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
 
@@ -46,6 +55,7 @@ struct TailShared {
     double rsd[64];
     int fail;
     int ok;
+    int tk;
 };
 static_assert(2 * sizeof(TailShared) <= 160 * 1024, "two tile workgroups per CU");
 
@@ -106,44 +116,54 @@ __device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsign
     return ok;
 }
 
-// host + device: blocks of tile column l = 1 (the pair) + the off-diagonal tiles below it that no pair owns
+// Work units: T "pairs" (column l: the diagonal tile (l,l) together with (l,l-1)) and the other off-diagonal tiles,
+// numbered column by column: column l holds the rows tail_first_row(l) .. R-1.
 __host__ __device__ inline int tail_first_row(int l, int T) { return (l + 1 < T) ? l + 2 : l + 1; }
-__host__ __device__ inline int tail_col_blocks(int l, int T, int R) {
+__host__ __device__ inline int tail_col_tiles(int l, int T, int R) {
     const int n = R - tail_first_row(l, T);
-    return 1 + (n > 0 ? n : 0);
+    return n > 0 ? n : 0;
 }
-inline int tail_grid(int T, int R) {
+__host__ __device__ inline int tail_tiles(int T, int R) {
     int n = 0;
-    for (int l = 0; l < T; ++l) n += tail_col_blocks(l, T, R);
+    for (int l = 0; l < T; ++l) n += tail_col_tiles(l, T, R);
     return n;
 }
 
 __global__ void __launch_bounds__(256, 2)
-tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __restrict__ sync, int* __restrict__ info,
-            unsigned long long* __restrict__ dbg) {
+tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, unsigned* __restrict__ sync,
+            int* __restrict__ info, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;
     unsigned* const abortw = sync;
-    auto flag = [&](int col, int row) { return sync + 4 + col * TAIL_MAXR + row; };
+    auto flag = [&](int col, int row) { return sync + 4 + col * R + row; };
     double* const W0 = W + (size_t)k0 * ld + k0;                  // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
-    // ---------------- which tile(s): column-major block order, the pair first in its column
+    const bool pair = (int)blockIdx.x < T;        // pair of column blockIdx.x: owns (tl,tl) and, for tl >= 1, (tl,tl-1)
+    if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
+    const int ntiles = tail_tiles(T, R);
+    unsigned* const ticketw = sync + 1;
+    bool alive = true;
+  for (;;) {     // a pair runs the body once; a worker once per ticket
     int tl = 0, ti;
-    {
-        int q = blockIdx.x;
+    if (pair) {
+        tl = ti = (int)blockIdx.x;
+    } else {
+        if (tid == 0) sh.tk = (int)__hip_atomic_fetch_add(ticketw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        int q = sh.tk;
+        __syncthreads();
+        if (q >= ntiles) break;
         for (;; ++tl) {
-            const int n = tail_col_blocks(tl, T, R);
+            const int n = tail_col_tiles(tl, T, R);
             if (q < n) break;
             q -= n;
         }
-        ti = (q == 0) ? tl : tail_first_row(tl, T) + q - 1;
+        ti = tail_first_row(tl, T) + q;
     }
-    const bool pair = (ti == tl);                 // owns (tl,tl) and, for tl >= 1, (tl, tl-1)
-    if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
     // diagnostic (dbg != nullptr only from gpmc_debug_tail_stamps): s_memtime stamps of the pair workgroups
 #define TAIL_STAMP(k)                                                                  \
     do {                                                                               \
@@ -172,11 +192,8 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __re
     for (int g = 0; g < 16; ++g) X[g] = (xl >= 0) ? sh.Ls[16 * w + c][4 * g + i] : 0.0;
     __syncthreads();
 
-    bool alive = true;
-    // ---------------- left-looking accumulation over the published columns
-    for (int col = 0; col < xl && alive; ++col) {
-        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid);
-        if (!alive) break;
+    // X -= L_{xi,col} L_{xl,col}^T (and, for the pair, (tl,tl) -= L_{tl,col} L_{tl,col}^T): both operands from W
+    auto accumulate = [&](int col) {
         tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
         tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
         __syncthreads();
@@ -195,7 +212,7 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __re
                     for (int g = 0; g < 8; ++g)
                         X[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aT[g][e2], bT[e2], X[gb + g], 0, 0, 0);
             }
-            if (pair) {     // (tl,tl) -= L_{tl,col} L_{tl,col}^T, rows of L_{tl,col} in Ls
+            if (pair) {     // rows of L_{tl,col} are in Ls
                 d2_t bD[4], aD[4];
 #pragma unroll
                 for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][ko]);
@@ -211,6 +228,40 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __re
             }
         }
         __syncthreads();
+    };
+    // the pair of column 0 has no off-diagonal tile: its diagonal tile takes the history alone
+    auto accumulate_D0 = [&](int col) {
+        tail_tile_in(sh.Ls, tile(tl, col), ld, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int ko = 8 * k8 + 2 * i;
+            d2_t bD[4], aD[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][ko]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][ko]);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int h = 0; h <= m; ++h)
+                        D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aD[m][e2], bD[h][e2], D[m][h], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+
+    // ---------------- left-looking accumulation: first the H history columns to the left of this launch's columns
+    // (final since an earlier launch: nothing to wait for), then this launch's columns as they are published
+    for (int col = -H; col < 0; ++col) {
+        if (xl >= 0) accumulate(col);
+        else accumulate_D0(col);
+    }
+    for (int col = 0; col < xl && alive; ++col) {
+        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid);
+        if (!alive) break;
+        accumulate(col);
     }
 
     // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
@@ -296,6 +347,9 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, unsigned* __re
         if (tid == 0) __hip_atomic_store(flag(tl, tl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TAIL_STAMP(8);
     }
+    if (pair || !alive) break;
+    __syncthreads();      // LDS is reused by the next ticket
+  }
     if (!alive && tid == 0) atomicCAS(info, 0, GPMC_TAIL_TIMEOUT);
 }
 
