@@ -615,8 +615,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
-    // the last columns as one tile-DAG launch (tail.h): f64, no trapezoidal riding rows
-    const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && ntri == 0 && fused && g_opt.panel_impl == 1;
+    // the last columns as one tile-DAG launch (tail.h): f64
+    const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && fused && g_opt.panel_impl == 1;
     auto use_tail = [&](int k0) {
         return tail_ok && np_ - k0 <= g_opt.tail_m && (np_ - k0) / NB_IN <= TAIL_MAXT &&
                tail_sync_words((np_ - k0) / NB_IN, (mp - k0) / NB_IN) * sizeof(unsigned) <= TAIL_SYNC_BYTES;
@@ -646,7 +646,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int ntl = tail_tiles(Tt, Rt);
         const int grid = Tt + (ntl < workers ? ntl : workers);
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), sizeof(TailShared), st,
-                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, sync, info_dev, g_tail_dbg);
+                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
+                           g_tail_dbg);
         GPMC_LAUNCH_CHECK();
         return 0;
     };
@@ -746,7 +747,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             rc = sc->edge_wait(s, pe);
             if (rc) return rc;
             if (k2 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp, np_, s, k2, np_, false, pad_la);
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_, false, pad_la);
                 if (rc) return rc;
                 rc = sc->edge_record(s, &ge);
                 if (rc) return rc;

@@ -130,7 +130,7 @@ __host__ __device__ inline int tail_tiles(int T, int R) {
 }
 
 __global__ void __launch_bounds__(256, 2)
-tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, unsigned* __restrict__ sync,
+tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
@@ -142,6 +142,12 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, unsigne
     double* const W0 = W + (size_t)k0 * ld + k0;                  // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
+    // Block rows >= tri0 are riding rows that are upper-trapezoidal on entry (gpmc_potrf_tri: riding row r is zero left
+    // of global column r).  Tile (i, col) of such a row is entirely zero -- before and after the factorisation -- when
+    // the launch's column col lies left of the block's first row index: it is never worked on, never published, and
+    // its updates of other tiles are skipped.  tri0 = R: no such rows.
+    const int gb = k0 / 64;
+    auto zero_tile = [&](int ti_, int col) { return ti_ >= tri0 && col + gb < ti_ - tri0; };
     const bool pair = (int)blockIdx.x < T;        // pair of column blockIdx.x: owns (tl,tl) and, for tl >= 1, (tl,tl-1)
     if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
     const int ntiles = tail_tiles(T, R);
@@ -163,6 +169,7 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, unsigne
             q -= n;
         }
         ti = tail_first_row(tl, T) + q;
+        if (zero_tile(ti, tl)) continue;
     }
     // diagnostic (dbg != nullptr only from gpmc_debug_tail_stamps): s_memtime stamps of the pair workgroups
 #define TAIL_STAMP(k)                                                                  \
@@ -255,10 +262,12 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, unsigne
     // ---------------- left-looking accumulation: first the H history columns to the left of this launch's columns
     // (final since an earlier launch: nothing to wait for), then this launch's columns as they are published
     for (int col = -H; col < 0; ++col) {
+        if (zero_tile(xi, col)) continue;
         if (xl >= 0) accumulate(col);
         else accumulate_D0(col);
     }
     for (int col = 0; col < xl && alive; ++col) {
+        if (zero_tile(xi, col)) continue;
         alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid);
         if (!alive) break;
         accumulate(col);
