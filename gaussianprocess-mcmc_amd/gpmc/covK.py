@@ -2,8 +2,8 @@
 
 Same protocol the reference sampler calls (kcMCMC/sliceSample.py:38-39,104-105,136-137,255,262-263;
 demoRegression.py:124-125): constructor takes LOG hyper-parameters, ``getCovMatrix`` returns a fresh
-dense matrix -- here a ``torch`` device tensor (float64 unless ``dtype`` says otherwise) filled by the
-``gpmc_kbuild`` HIP kernel.  ``.numpy()`` on the result gives the reference's ndarray.
+dense matrix -- a ``torch`` device tensor (float64 unless ``dtype`` says otherwise) filled by the
+``gpmc_kbuild`` HIP kernel, or, after ``gpmc.set_return('numpy')``, the reference's fresh host ndarray.
 """
 import numpy as np
 import torch
@@ -27,7 +27,7 @@ class Kernel(object):
     def getCovMatrix(self, x=None, z=None, mode=None, diag_add=0.0, out=None):
         if mode == 'self_test':                       # only the diagonal of k(z, z): sf2 for both families
             nn = _x2d(z, self.dtype).shape[0]
-            return torch.full((nn, 1), float(self.kparams()[0]), dtype=self.dtype, device=ops.device())
+            return ops.ret(torch.full((nn, 1), float(self.kparams()[0]), dtype=self.dtype, device=ops.device()))
         if mode not in ('train', 'cross'):
             raise ValueError("mode must be 'train', 'cross' or 'self_test'")
         X = _x2d(x, self.dtype)
@@ -35,10 +35,11 @@ class Kernel(object):
         n = X.shape[0]
         m = n if Z is None else Z.shape[0]
         kp = ops.to_dev(self.kparams(diag_add if mode == 'train' else 0.0), self.dtype)
+        caller_out = out is not None
         if out is None:
             out = torch.empty((n, m), dtype=self.dtype, device=X.device)
         ops.kbuild(self.kind, X, kp, out, n, m, ops.KB_FULL, Z=Z)
-        return out
+        return out if caller_out else ops.ret(out)
 
 
 class RBF(Kernel):

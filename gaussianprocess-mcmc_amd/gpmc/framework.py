@@ -10,7 +10,7 @@ DEMO_HYP0 = (0.35, 2.0, 0.2)             # demoRegression.py:15
 SCALE = (10., 10., 5.)                   # framework.py:69, demoRegression.py:25
 
 
-def run_chain(x, y, iters, hyp0, scale=SCALE, iter0=0, verbose=False, workspace=None):
+def run_chain(x, y, iters, hyp0, scale=SCALE, iter0=0, verbose=False, workspace=None, margins=None):
     y = np.asarray(y, dtype=np.float64).reshape(-1)
     propHyp = np.asarray(hyp0, dtype=np.float64)
     propF = np.zeros_like(y)
@@ -27,6 +27,8 @@ def run_chain(x, y, iters, hyp0, scale=SCALE, iter0=0, verbose=False, workspace=
         histF[:, i] = propF
         histHyp[:, i] = propHyp
         ntries[i] = st['proposals']
+        if margins is not None:             # per iteration: proposal - threshold of every try
+            margins.append(list(st['margins']))
     return histF, histHyp, ntries
 
 
@@ -226,7 +228,7 @@ def synthetic_demo_data(n=455, seed=124, ll=5.0, sf=20.0, sn=2.5, mean=91.153846
     np.random.seed(seed)
     x = np.arange(0, n).astype(np.float64).reshape(n, 1)
     K = covK.RBF(np.log(ll), np.log(sf)).getCovMatrix(x, mode='train', diag_add=sn ** 2)
-    L = tools.jitchol(K)
+    L = ops.to_dev(tools.jitchol(K))             # (a tensor whatever gpmc.set_return says)
     z = ops.to_dev(np.random.normal(size=(n,)))
     y = torch.mv(L, z).cpu().numpy() + mean      # one O(N^2) product to draw the data, not on the hot path
     return x, y

@@ -21,6 +21,28 @@ def device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+# ---- what the kcGP-protocol mirrors hand back: 'torch' (device tensors, default) or 'numpy' (fresh host ndarrays, so
+# that NumPy code written against the reference's kcGP -- np.diagonal(K), np.linalg.solve(L, K), sliceSample.py:182-205 --
+# runs on top unchanged; costs one D2H copy per returned matrix)
+_RETURN = 'torch'
+
+
+def set_return(mode):
+    global _RETURN
+    if mode not in ('torch', 'numpy'):
+        raise ValueError("return mode must be 'torch' or 'numpy'")
+    _RETURN = mode
+
+
+def get_return():
+    return _RETURN
+
+
+def ret(t):
+    """a result of a protocol mirror in the configured return form"""
+    return t.cpu().numpy() if _RETURN == 'numpy' else t
+
+
 def sfx(dtype):
     if dtype == torch.float64:
         return 'f64'

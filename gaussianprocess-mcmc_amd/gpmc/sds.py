@@ -187,13 +187,34 @@ class SDSWorkspace(object):
         return ops.unpack_lower(self.WR, self.np_, self.n)
 
 
+def jitter_schedule(attempt, diag, maxtries=5):
+    """The failure handling of pyGPs 1.3.4 ``jitchol`` (the version the reference pins, requirements.txt:10; call
+    sites sliceSample.py:196,205), shared by SDSWorkspace-free callers: ``attempt(jitter)`` factors the matrix with
+    ``jitter`` added to its diagonal and returns LAPACK-style info.  attempt(0) first; on failure every diagonal
+    element must be positive, then jitter = mean(diag) * 1e-9, x10 per retry, ``maxtries`` retries, then
+    LinAlgError.  Returns the jitter that worked."""
+    if attempt(0.0) == 0:
+        return 0.0
+    if bool((diag <= 0).any()):
+        raise np.linalg.LinAlgError('not pd: non-positive diagonal elements')
+    jitter = float(diag.mean()) * 1e-9
+    for _ in range(maxtries):
+        if attempt(jitter) == 0:
+            return jitter
+        jitter *= 10.
+    raise np.linalg.LinAlgError('not positive definite, even with jitter.')
+
+
 def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     """Protocol-compatible ``aux_var_model(f, K, sn, g=None)`` -> (g, K+S, m_theta_g, chol_R_theta, L)
-    for a dense K handed in by the caller (ndarray or device tensor); everything returned is a device
-    tensor.  Slower than SDSWorkspace (K is packed instead of built in place) -- it exists so code written
-    against the reference's function keeps working.  Same inverse form as SDSWorkspace, here with the general
-    (vector) S of sliceSample.py:183-190: riding rows diag(S) come back as P = S L^-T, R = diag(S) - P P^T,
-    m = g - P (L^-1 g)."""
+    for a dense K handed in by the caller (ndarray or device tensor); returns device tensors, or ndarrays after
+    ``gpmc.set_return('numpy')``.  Slower than SDSWorkspace (K is packed instead of built in place) -- it exists so
+    code written against the reference's function keeps working.  Same inverse form as SDSWorkspace, here with the
+    general (vector) S of sliceSample.py:183-190: riding rows diag(S) come back as P = S L^-T, R = diag(S) - P P^T,
+    m = g - P (L^-1 g).  Both factorisations go through ``jitter_schedule`` as the reference's go through jitchol
+    (sliceSample.py:196,205).  As in the reference the K+S that is RETURNED is the unjittered one (:207); a jitter j
+    that chol(K+S) needed acts as S' = S + j I in R and m = R S^-1 g (algebraically the reference's
+    K - K (K+S+jI)^-1 K)."""
     Kd = ops.to_dev(K)
     n = Kd.shape[0]
     dev, dt = Kd.device, Kd.dtype
@@ -210,25 +231,39 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     # workspace: [K + S ; g block ; diag(S) rows]  (layout of SDSWorkspace form 'inv')
     mpA = 2 * np_ + ops.PAD
     WA = torch.zeros((mpA, np_), dtype=dt, device=dev)
-    ops.pack_lower(KS, WA, np_, 0.0)
-    WA[np_, :n].copy_(g)
     rows = WA[np_ + ops.PAD:]
-    torch.diagonal(rows)[:n].copy_(Sii)
-    if np_ > n:
-        torch.diagonal(rows)[n:].fill_(1.0)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     scratch = ops.potrf_scratch(np_, dev)
-    ops.potrf_tri(WA, mpA, np_, np_, info, scratch)
-    if _lib.check_info(info.item()) != 0:
-        raise np.linalg.LinAlgError('K + S not positive definite (pivot %d)' % int(info.item()))
+
+    def factor_A(jitter):
+        ops.pack_lower(KS, WA, np_, jitter)
+        WA[np_:].zero_()
+        WA[np_, :n].copy_(g)
+        torch.diagonal(rows)[:n].copy_(Sii + jitter)
+        if np_ > n:
+            torch.diagonal(rows)[n:].fill_(1.0)
+        ops.potrf_tri(WA, mpA, np_, np_, info, scratch)
+        return _lib.check_info(info.item())
+
+    jA = jitter_schedule(factor_A, torch.diagonal(KS))
     L = ops.unpack_lower(WA, np_, n)
-    WR = torch.zeros((np_ + ops.PAD, np_), dtype=dt, device=dev)
-    ops.syrk_tri(rows, WR, n, np_, 0.0)                      # -P P^T (identity on the padding)
-    WR.diagonal()[:n].add_(Sii + R_JITTER)                   # R + 1e-11 I = diag(S) - P P^T + 1e-11 I
+    SA = Sii + jA
     m = torch.empty(n, dtype=dt, device=dev)
-    ops.trmv_upper(rows, n, WA[np_], g, -1.0, m)
-    ops.potrf(WR, np_ + ops.PAD, np_, info, scratch)
-    if _lib.check_info(info.item()) != 0:
-        raise np.linalg.LinAlgError('R not positive definite (pivot %d)' % int(info.item()))
+    ops.trmv_upper(rows, n, WA[np_], g, -1.0, m)             # g - P alpha
+    if jA:
+        m.mul_(SA / Sii)                                     # R S^-1 g with the unjittered S (sliceSample.py:204)
+    WR = torch.zeros((np_ + ops.PAD, np_), dtype=dt, device=dev)
+    R0 = torch.empty((np_, np_), dtype=dt, device=dev)
+    ops.syrk_tri(rows, R0, n, np_, 0.0)                      # -P P^T (identity on the padding)
+    R0.diagonal()[:n].add_(SA)                               # R = diag(S') - P P^T
+
+    def factor_R(jitter):
+        WR[:np_].copy_(R0)
+        WR[np_:].zero_()
+        WR.diagonal()[:n].add_(R_JITTER + jitter)            # R + 1e-11 I (sliceSample.py:205) + the schedule's jitter
+        ops.potrf(WR, np_ + ops.PAD, np_, info, scratch)
+        return _lib.check_info(info.item())
+
+    jitter_schedule(factor_R, R0.diagonal()[:n] + R_JITTER)
     C = ops.unpack_lower(WR, np_, n)
-    return g, KS, m, C, L
+    return tuple(ops.ret(t) for t in (g, KS, m, C, L))

@@ -34,13 +34,18 @@ def log_gamma(x, k, theta, invG):
 
 
 def workspace_for(x):
-    """One SDSWorkspace per training-input array (keyed by identity and shape), so the chain drivers'
-    repeated calls reuse ~3 N^2 of device memory instead of reallocating it."""
-    key = (id(x), tuple(np.shape(x)))
-    ws = _ws_cache.get(key)
-    if ws is None:
-        _ws_cache.clear()
-        ws = _ws_cache[key] = SDSWorkspace(x)
+    """One SDSWorkspace per training-input array, so the chain drivers' repeated calls reuse ~3 N^2 of device memory
+    instead of reallocating it.  The entry holds a strong reference to the array it was built from AND a copy of its
+    contents: a hit needs the same object with unchanged values (an id() alone can be recycled by a later temporary of
+    the same shape -- e.g. fold slices ``x[train_id, :]`` -- and in-place edits would go unseen)."""
+    ent = _ws_cache.get('ws')
+    if ent is not None:
+        x_ref, x_copy, ws = ent
+        if x_ref is x and np.shape(x) == x_copy.shape and np.array_equal(np.asarray(x), x_copy):
+            return ws
+    _ws_cache.clear()
+    ws = SDSWorkspace(x)
+    _ws_cache['ws'] = (x, np.array(x, dtype=np.float64, copy=True), ws)
     return ws
 
 
@@ -91,6 +96,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
         threshold += prior[2]
 
     ntry = 0
+    margins = []            # proposal - threshold of every try (stats only: how close each decision was)
     while True:
         if ntry >= MAX_SHRINK:
             raise RuntimeError('surrogate_slice_sampling: no acceptable proposal after %d shrink steps' % ntry)
@@ -108,15 +114,34 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
         if iter >= NOISE_FREEZE_ITERS:
             proposal += propPrior[2]
 
+        margins.append(proposal - threshold)
         if proposal > threshold and np.isfinite(proposal):
             if stats is not None:
                 stats['proposals'] = ntry
+                stats['margins'] = margins
             return prop_f, prop_hyp
         for i in range(0, 3):
             if prop_hyp[i] < hyp[i]:
                 hyp_min[i] = prop_hyp[i]
             else:
                 hyp_max[i] = prop_hyp[i]
+
+
+def draw_prior(x, hyp, size=None):
+    """nu ~ N(0, K(hyp)) as chol(K) z on the device (gpmc_kbuild + gpmc_potrf + gpmc_trmv_lower), z from the legacy
+    ``np.random`` stream (n normals per draw, like the reference's ``multivariate_normal(0, K, 1)``, sliceSample.py:41).
+    ``size=None``: one draw, shape (n,); else (size, n) from ONE factorisation."""
+    from . import covK, tools
+    K = covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+    L = ops.to_dev(tools.jitchol(K))                           # jitter schedule covers the numerically singular K
+    nobs = L.shape[0]
+    out = np.empty((1 if size is None else int(size), nobs))
+    nu_d = torch.empty(nobs, dtype=torch.float64, device=L.device)
+    for r in range(out.shape[0]):
+        z = ops.to_dev(np.random.standard_normal(nobs))
+        ops.trmv_lower(L, nobs, z, None, nu_d)
+        out[r] = nu_d.cpu().numpy()
+    return out[0] if size is None else out
 
 
 def elliptical_slice(f, x, y, hyp, nu=None):
@@ -126,18 +151,12 @@ def elliptical_slice(f, x, y, hyp, nu=None):
     from the legacy ``np.random`` stream; the reference uses ``multivariate_normal`` (an SVD of K), which consumes
     the same number of normals but maps them differently, so chains are equal in distribution, not draw for draw.
     The angle bracket loop is the reference's, draw for draw."""
-    from . import covK, tools
     f = np.asarray(f, dtype=np.float64).reshape(-1)
     y = np.asarray(y, dtype=np.float64).reshape(-1)
     nobs = f.shape[0]
     my = np.mean(y)
     if nu is None:
-        K = covK.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
-        L = tools.jitchol(K)                                   # jitter schedule covers the numerically singular K
-        z = ops.to_dev(np.random.standard_normal(nobs))
-        nu_d = torch.empty(nobs, dtype=torch.float64, device=L.device)
-        ops.trmv_lower(L, nobs, z, None, nu_d)
-        nu = nu_d.cpu().numpy()
+        nu = draw_prior(x, hyp)
     lik_func = likK.TruncatedGauss2(upper=Y_UPPER - my, lower=Y_LOWER - my, log_sigma=np.log(hyp[2]))
     cur_llk = lik_func.evaluate(y=y - my, mu=f)
     _check_finite_start(cur_llk)
@@ -195,7 +214,7 @@ def inf_mcmc(f, model, ys=0):
     if int(info.item()) != 0:
         raise np.linalg.LinAlgError('K/sn2 + I not positive definite (pivot %d)' % int(info.item()))
     Vt = W[np_ + r1:np_ + r1 + ns, :n]
-    kss = cov.getCovMatrix(z=xs, mode='self_test')
+    kss = ops.to_dev(cov.getCovMatrix(z=xs, mode='self_test'))
     fs2 = kss - (Vt * Vt).sum(dim=1, keepdim=True)          # O(ns n) reduction
     Fs2 = torch.clamp(fs2, min=0.)
     # alpha^T = (L^-1 (f - m))^T L^-1 / sn2 : backward half on the reverse-transposed factor

@@ -49,7 +49,7 @@ def jitchol(A, maxtries=5, workspace=None):
         ops.pack_rows(None, ws.W, ws.mp, ws.np_, n)
     ws.factor()
     if ws.info_host() == 0:
-        return ops.unpack_lower(ws.W, ws.np_, n)
+        return ops.ret(ops.unpack_lower(ws.W, ws.np_, n))
     diagA = torch.diagonal(A)
     if bool((diagA <= 0).any()):
         raise np.linalg.LinAlgError('not pd: non-positive diagonal elements')
@@ -60,7 +60,7 @@ def jitchol(A, maxtries=5, workspace=None):
             ops.pack_rows(None, ws.W, ws.mp, ws.np_, n)
         ws.factor()
         if ws.info_host() == 0:
-            return ops.unpack_lower(ws.W, ws.np_, n)
+            return ops.ret(ops.unpack_lower(ws.W, ws.np_, n))
         jitter *= 10.
     raise np.linalg.LinAlgError('not positive definite, even with jitter.')
 
@@ -93,4 +93,4 @@ def solve_chol(L, B):
     Rj = R.flip(1).contiguous()                                # rows J  (data movement only)
     ops.trsm_rows(Wt, np_, Rj, mr)
     X = Rj.flip(1)[:m, :n].t().contiguous()
-    return X.reshape(-1) if vec else X
+    return ops.ret(X.reshape(-1) if vec else X)

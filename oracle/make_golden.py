@@ -121,6 +121,45 @@ def golden_trace(ref, out, name, n, d, iters, hyp0, seed, iter0=0):
     print('%s: n=%d iters=%d proposals=%d' % (name, n, iters, ntries.sum()))
 
 
+def golden_trace_demo(ref, out, name, n, iters, seed):
+    """Seeded chain at the reference's own demo sizes: data of the demoRegression.py:118-131 generator (seed 124, ll=5,
+    sf=20, sn=2.5, x = arange(n); n = 455 there, BASELINE config 1 says ~200) clipped to the 1..99 score range, the
+    demo's initial point (demoRegression.py:15), driven by the REFERENCE sampler.  Also stored, clearly marked as the
+    ORACLE's (sds_ref literal restatement, same seed -- it reproduces the reference's decisions exactly, which this
+    function asserts): the margin proposal - threshold of every try, i.e. how close each accept/shrink decision was."""
+    x, y = sds_ref.synthetic_demo_data(n, 124)
+    y = np.clip(y, 1., 99.)
+    kcgp_ref.covK.RBF = _CountingRBF
+    try:
+        np.random.seed(seed)
+        hyp = np.asarray(sds_ref.DEMO_HYP0, dtype=np.float64)
+        f = np.zeros_like(y)
+        histF = np.zeros((n, iters))
+        histHyp = np.zeros((3, iters))
+        ntries = np.zeros(iters, dtype=np.int64)
+        for i in range(iters):
+            _CountingRBF.count = 0
+            f, hyp = ref.surrogate_slice_sampling(f, x, y, hyp, scale=np.asarray([10., 10., 5.]), iter=i)
+            histF[:, i] = f
+            histHyp[:, i] = hyp
+            ntries[i] = _CountingRBF.count - 1
+        rng_tail = np.random.uniform(size=4)
+    finally:
+        kcgp_ref.covK.RBF = _REAL_RBF
+    np.random.seed(seed)
+    marg = []
+    oF, oH, oN = sds_ref.run_chain(x, y, iters, sds_ref.DEMO_HYP0, literal=True, margins=marg)
+    assert np.array_equal(oN, ntries) and np.array_equal(oH, histHyp), 'oracle restatement left the reference trace'
+    width = int(ntries.max())
+    margins = np.full((iters, width), np.nan)
+    for i, row in enumerate(marg):
+        margins[i, :len(row)] = row
+    np.savez_compressed(os.path.join(out, name), x=x, y=y, hyp0=np.asarray(sds_ref.DEMO_HYP0), seed=seed, iters=iters,
+                        iter0=0, histF=histF, histHyp=histHyp, ntries=ntries, rng_tail=rng_tail,
+                        oracle_margins=margins)
+    print('%s: n=%d iters=%d proposals=%d  smallest |margin| %.3e' % (name, n, iters, ntries.sum(), np.nanmin(np.abs(margins))))
+
+
 def golden_inf_mcmc(ref, out):
     """the reference's own inf_mcmc (sliceSample.py:234-284) on a small model object"""
     x, y = make_xy(60, 1, 77)
@@ -171,6 +210,8 @@ def main():
     golden_trace(ref, a.out, 'trace_demo_n48_d2.npz', 48, 2, 10, sds_ref.DEMO_HYP0, 11)
     golden_trace(ref, a.out, 'trace_unfreeze_n8.npz', 8, 1, 520, sds_ref.FRAMEWORK_HYP0, 99)
     golden_trace(ref, a.out, 'trace_late_n32.npz', 32, 1, 8, sds_ref.FRAMEWORK_HYP0, 5, iter0=498)
+    golden_trace_demo(ref, a.out, 'trace_demo_n200.npz', 200, 30, 5)
+    golden_trace_demo(ref, a.out, 'trace_demo_n455.npz', 455, 20, 5)
     golden_inf_mcmc(ref, a.out)
     golden_elliptical(ref, a.out)
     golden_synthetic(a.out)

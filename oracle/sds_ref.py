@@ -143,7 +143,8 @@ def _check_finite_start(cur_llk):
 def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=None):
     """One SDS update of (f, hyp) -- sliceSample.py:76-163, draw for draw.
 
-    ``stats`` (optional dict) receives the number of proposals evaluated.
+    ``stats`` (optional dict) receives the number of proposals evaluated and the margin
+    ``proposal - threshold`` of every try (how close each accept/shrink decision was).
     RNG order on the global legacy stream: N normals (g), 3 uniforms (bracket),
     1 uniform (slice height), then 3 uniforms per proposal.
     """
@@ -171,6 +172,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=No
         threshold += prior[2]
 
     ntry = 0
+    margins = []
     while True:
         ntry += 1
         prop_hyp = np.random.uniform(low=hyp_min, high=hyp_max)
@@ -186,9 +188,11 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=No
         proposal = prop_llk + pp[1] + pp[0] + propG
         if iter >= NOISE_FREEZE_ITERS:
             proposal += pp[2]
+        margins.append(proposal - threshold)
         if proposal > threshold and np.isfinite(proposal):
             if stats is not None:
                 stats['proposals'] = ntry
+                stats['margins'] = margins
             return prop_f, prop_hyp
         for i in range(3):
             if prop_hyp[i] < hyp[i]:
@@ -198,10 +202,11 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, literal=True, stats=No
 
 
 # --------------------------------------------------------------------------- chain drivers
-def run_chain(x, y, iters, hyp0, scale=(10., 10., 5.), literal=True, iter0=0):
+def run_chain(x, y, iters, hyp0, scale=(10., 10., 5.), literal=True, iter0=0, margins=None):
     """Shape of Framework.runSimulMCMC (framework.py:59-77) / mcmcUpdate (demoRegression.py:15-32).
 
-    Returns histF (n, iters), histHyp (3, iters), proposals (iters,).
+    Returns histF (n, iters), histHyp (3, iters), proposals (iters,); ``margins`` (optional list) receives, per
+    iteration, the list of ``proposal - threshold`` values of its tries.
     """
     y = np.asarray(y, dtype=np.float64).reshape(-1)
     hyp = np.asarray(hyp0, dtype=np.float64)
@@ -216,6 +221,8 @@ def run_chain(x, y, iters, hyp0, scale=(10., 10., 5.), literal=True, iter0=0):
         histF[:, i] = f
         histHyp[:, i] = hyp
         ntries[i] = st['proposals']
+        if margins is not None:
+            margins.append(list(st['margins']))
     return histF, histHyp, ntries
 
 

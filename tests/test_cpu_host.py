@@ -96,6 +96,33 @@ print('rank', out['rank'], 'ok')
 '''
 
 
+def test_truncated_gauss_against_scipy_truncnorm():
+    """An independent pin for likK.TruncatedGauss2 (a14; the class is absent from the reference, semantics inferred
+    from its call sites): log-density, mean and the 2.5 % / 97.5 % quantiles of a Gaussian(mu, sqrt(sn^2 + s2))
+    truncated to [lower, upper] against scipy.stats.truncnorm, and -inf outside the bounds."""
+    from scipy.stats import truncnorm
+    from gpmc import likK
+    rng = np.random.RandomState(1)
+    lo, up, sn = -42.5, 57.5, 1.7
+    mu = rng.uniform(-45, 60, 200)
+    y = np.clip(mu + sn * rng.standard_normal(200), lo + 1e-3, up - 1e-3)
+    lik = likK.TruncatedGauss2(upper=up, lower=lo, log_sigma=np.log(sn))
+    a, b = (lo - mu) / sn, (up - mu) / sn
+    ref = truncnorm.logpdf(y, a, b, loc=mu, scale=sn).sum()
+    assert abs(lik.evaluate(y=y, mu=mu) - ref) <= 1e-10 * abs(ref)
+    y_out = y.copy(); y_out[7] = up + 0.5
+    assert lik.evaluate(y=y_out, mu=mu) == -np.inf
+    s2 = rng.uniform(0.1, 4.0, 200)
+    sd = np.sqrt(sn ** 2 + s2)
+    a, b = (lo - mu) / sd, (up - mu) / sd
+    ymu, lw, hi = lik.evaluate(mu=mu, s2=s2)
+    np.testing.assert_allclose(ymu, truncnorm.mean(a, b, loc=mu, scale=sd), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(lw, truncnorm.ppf(0.025, a, b, loc=mu, scale=sd), rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(hi, truncnorm.ppf(0.975, a, b, loc=mu, scale=sd), rtol=1e-8, atol=1e-8)
+    ref2 = truncnorm.logpdf(y, a, b, loc=mu, scale=sd).sum()
+    assert abs(lik.evaluate(y=y, mu=mu, s2=s2) - ref2) <= 1e-10 * abs(ref2)
+
+
 def test_chain_gather_world_size_2_gloo(tmp_path):
     """N > 1 path: one chain per rank, seeds base + rank, one all_gather of the histories (gloo, CPU)."""
     script = tmp_path / 'worker.py'

@@ -64,15 +64,29 @@ def test_elliptical_slice_given_nu_matches_reference_fixture(golden_dir):
 
 
 def test_elliptical_slice_device_draw_has_prior_covariance():
-    """nu = chol(K) z on the device: the update keeps f on the prior ellipse and moves it"""
+    """nu = chol(K) z on the device is equal IN DISTRIBUTION to the reference's multivariate_normal(0, K) (an SVD of K,
+    sliceSample.py:41): over 4000 draws at n = 16 the sample mean is 0 and the sample covariance is K, entry by entry,
+    within 5 standard errors (se of an entry of the sample covariance of a Gaussian: sqrt((K_ii K_jj + K_ij^2) / M));
+    and one update stays on the prior ellipse and moves."""
     from gpmc import sliceSample
+    from oracle.kcgp_ref import covK as ocov
     rng = np.random.RandomState(5)
-    n = 120
+    n, M = 16, 4000
     x = np.sort(rng.uniform(0, 10, (n, 1)), axis=0)
+    hyp = np.array([1.0, 10.0, 1.2])
+    K = ocov.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+    np.random.seed(11)
+    nu = sliceSample.draw_prior(x, hyp, size=M)
+    assert nu.shape == (M, n)
+    se_mean = np.sqrt(np.diag(K) / M)
+    assert np.all(np.abs(nu.mean(axis=0)) <= 5 * se_mean)
+    S = nu.T @ nu / M
+    se = np.sqrt((np.outer(np.diag(K), np.diag(K)) + K ** 2) / M)
+    assert np.all(np.abs(S - K) <= 5 * se), float((np.abs(S - K) / se).max())
     y = np.clip(50 + 10 * np.sin(x[:, 0]) + rng.standard_normal(n), 1, 99)
     f = y - y.mean()
     np.random.seed(9)
-    f1 = sliceSample.elliptical_slice(f, x, y, np.array([1.0, 10.0, 1.2]))
+    f1 = sliceSample.elliptical_slice(f, x, y, hyp)
     assert f1.shape == (n,) and np.all(np.isfinite(f1)) and not np.allclose(f1, f)
 
 

@@ -76,6 +76,34 @@ def test_aux_var_model_device_vs_reference_fixture(golden_dir, gp, n, form):
     np.testing.assert_allclose(fp, z['f'], rtol=0, atol=1e-6 * max(1.0, np.abs(z['f']).max()))
 
 
+@pytest.mark.parametrize('n', [8, 64, 200])
+def test_whitened_latent_and_proposal_against_reference_fixture(golden_dir, gp, n):
+    """a9 / a10 against what the reference computed: ita = solve(C, f - m) (sliceSample.py:108) and
+    prop_f = C ita + m (:140), stored by oracle/make_golden.py.
+
+    n = 8, 64 (R well conditioned: min diag(C) 0.6 / 0.4): eta must equal the reference's ita to 1e-8 relative, and the
+    DEVICE factor applied to the REFERENCE's ita must land on the reference's prop_f to 1e-9.
+    n = 200 (1-D sorted inputs): the reference's own C has min diag 4.1e-6 and its ita reaches 5.6e5 -- R = K - V^T V has
+    eigenvalues at rounding level, and nothing that mixes two factorisations of it is stable: the CPU lean restatement
+    (same mathematics, other operation order) is already 4.2e3 away from the reference's ita and 175 away in
+    C_lean ita_ref + m - prop_f_ref.  There only backward-stable statements are asserted: C C^T = R_ref (the companion
+    test above), m to 1e-8, and that the fixture really is in that regime -- so the regime is pinned, not a tolerance."""
+    z = _load(golden_dir, 'aux_n%d.npz' % n)
+    ws = gp['sds'].SDSWorkspace(z['x'])
+    f, g = torch.as_tensor(z['f']).cuda(), torch.as_tensor(z['g_in']).cuda()
+    ws.aux_var_model(f, z['hyp'], g, need_eta=True)
+    eta = ws.eta.clone()
+    if n < 200:
+        np.testing.assert_allclose(eta.cpu().numpy(), z['ita'], rtol=0, atol=1e-8 * np.abs(z['ita']).max())
+        prop = ws.propose_f(torch.as_tensor(z['ita']).cuda()).cpu().numpy()
+        np.testing.assert_allclose(prop, z['prop_f'], rtol=0, atol=1e-9 * max(1.0, np.abs(z['prop_f']).max()))
+    else:
+        assert np.diag(z['C']).min() < 1e-5 and np.abs(z['ita']).max() > 1e5        # the ill-conditioned regime
+        np.testing.assert_allclose(ws.m.cpu().numpy(), z['m'], rtol=0, atol=1e-8 * np.abs(z['m']).max())
+        own = ws.propose_f(eta).cpu().numpy()                                       # the device's own round trip
+        np.testing.assert_allclose(own, z['f'], rtol=0, atol=1e-6 * max(1.0, np.abs(z['f']).max()))
+
+
 def test_aux_var_model_protocol_function(golden_dir, gp):
     """the reference-shaped function aux_var_model(f, K, sn, g) on a dense K"""
     z = _load(golden_dir, 'aux_n64.npz')
@@ -128,6 +156,132 @@ def test_seeded_chain_follows_reference_trace(golden_dir, gp, name):
     tail = np.random.uniform(size=4)
     np.testing.assert_array_equal(ntries, z['ntries'])
     np.testing.assert_allclose(histHyp, z['histHyp'], rtol=1e-12)
+    np.testing.assert_array_equal(tail, z['rng_tail'])
+    np.testing.assert_allclose(histF, z['histF'], rtol=0, atol=5e-2)
+
+
+@pytest.mark.parametrize('name,min_same', [('trace_demo_n200.npz', 30), ('trace_demo_n455.npz', 10)])
+def test_seeded_chain_at_the_reference_sizes(golden_dir, gp, name, min_same, record_property):
+    """Chains at the reference's own sizes (demoRegression.py:118-131 generator: 455 points; BASELINE config 1: ~200),
+    run by the reference sampler (fixture), replayed on the device with the same seed.
+
+    What must hold: identical accept/shrink decisions and hyper-parameters (1e-9) for the first ``min_same`` iterations
+    -- all 30 at N = 200.  At N = 455 even the CPU lean restatement (same mathematics as the reference, other operation
+    order) leaves the reference's path at iteration 18: with hyper-parameters bit-identical and f within 5e-4 up to
+    there, the proposal values of that iteration already differ by up to 3.8 between the two CPU forms at the same try
+    (the map f -> prop_f = C' eta + m' goes through the rounding-level spectrum of R).  So beyond ``min_same`` the test
+    records where the device diverges (if it does) and checks the divergence is of that kind: every decision margin of
+    that iteration, up to the first try decided differently, is within 2 % + 6 of the reference's."""
+    z = _load(golden_dir, name)
+    np.random.seed(int(z['seed']))
+    marg = []
+    histF, histHyp, ntries = gp['framework'].run_chain(z['x'], z['y'], int(z['iters']), z['hyp0'], margins=marg)
+    same = ntries == z['ntries']
+    first = int(z['iters']) if same.all() else int(np.argmin(same))
+    record_property('first_divergent_iteration', first)
+    assert first >= min_same, (first, ntries, z['ntries'])
+    np.testing.assert_allclose(histHyp[:, :first], z['histHyp'][:, :first], rtol=1e-9)
+    np.testing.assert_allclose(histF[:, :first], z['histF'][:, :first], rtol=0, atol=5e-2)
+    if first < int(z['iters']):
+        ref = z['oracle_margins'][first][:int(z['ntries'][first])]
+        dev = np.asarray(marg[first])
+        k = min(len(ref), len(dev))
+        flips = np.nonzero((ref[:k] > 0) != (dev[:k] > 0))[0]
+        upto = int(flips[0]) + 1 if len(flips) else k
+        record_property('margins_ref', ref[:upto].tolist())
+        record_property('margins_dev', dev[:upto].tolist())
+        assert np.all(np.abs(dev[:upto] - ref[:upto]) <= 0.02 * np.abs(ref[:upto]) + 6.0), (first, ref[:upto], dev[:upto])
+    else:
+        np.testing.assert_array_equal(np.random.uniform(size=4), z['rng_tail'])
+
+
+def test_workspace_cache_is_keyed_by_object_and_contents(gp):
+    """surrogate_slice_sampling(f, x, ...) with the reference signature reuses one SDSWorkspace per input array; the
+    cache must not hand a stale workspace to a different array that recycled the id, nor miss in-place edits."""
+    ss = gp['sliceSample']
+    x = np.random.RandomState(0).uniform(0, 10, (40, 1))
+    w1 = ss.workspace_for(x)
+    assert ss.workspace_for(x) is w1
+    x[3, 0] += 0.5                                            # in-place edit: same object, other contents
+    w2 = ss.workspace_for(x)
+    assert w2 is not w1 and abs(float(w2.X[3, 0]) - x[3, 0]) == 0.0
+    xa = x[np.arange(40) % 2 == 0, :]                         # temporaries of equal shape (fold slices)
+    wa = ss.workspace_for(xa)
+    xb = x[np.arange(40) % 2 == 1, :]
+    wb = ss.workspace_for(xb)
+    assert wb is not wa and np.array_equal(wb.X.cpu().numpy(), xb)
+
+
+def test_jittered_K_plus_S_is_used_consistently(gp):
+    """Drives infoA != 0 (VERDICT weak #5).  Coincident inputs and a tiny noise make K + S numerically singular, so
+    chol(K + S) goes through the jitchol schedule (mean(diag) * 1e-9, x10 per retry).  The reference then mixes two
+    matrices: log-det from the JITTERED factor, quadratic form from an LU inverse of the UNJITTERED, numerically
+    non-positive-definite K_S (sliceSample.py:196,207,122/147).  The device evaluates log N(g; 0, K + S + j I) with the
+    jittered matrix in both terms -- a deliberate, documented deviation: an LU inverse of a singular matrix is not
+    reproducible across BLAS builds.  Pinned here: the jitter level follows the schedule and the value equals SciPy's
+    for the jittered matrix."""
+    import scipy.linalg
+    from oracle.kcgp_ref import covK as ocov
+    rng = np.random.RandomState(3)
+    n = 96
+    x = np.repeat(rng.uniform(0, 10, (n // 4, 1)), 4, axis=0)          # every point four times
+    hyp = np.array([1.0, 10.0, 1e-7])
+    f = torch.zeros(n, dtype=torch.float64, device='cuda')
+    g = torch.as_tensor(rng.standard_normal(n)).cuda()
+    ws = gp['sds'].SDSWorkspace(x)
+    G = ws.aux_var_model(f, hyp, g, need_eta=False)
+    jitter = ws._sA - ws.Sii
+    assert jitter > 0                                                   # the schedule ran
+    sched = [(100.0 + ws.Sii) * 1e-9 * 10 ** k for k in range(5)]
+    assert min(abs(jitter - s) / s for s in sched) < 1e-12, (jitter, sched)
+    K = ocov.RBF(np.log(hyp[0]), np.log(hyp[1])).getCovMatrix(x=x, mode='train')
+    A = K + (ws.Sii + jitter) * np.eye(n)
+    L = scipy.linalg.cholesky(A, lower=True)
+    ref = sds_ref.log_marginal_lean(g.cpu().numpy(), L)
+    assert abs(G - ref) <= 1e-6 * abs(ref), (G, ref)                    # cond(A) ~ 1e10 here: 1e-6, not 1e-8
+
+
+def test_protocol_aux_var_model_follows_the_jitter_schedule(gp):
+    """ADVICE (low): the drop-in aux_var_model(f, K, sn, g) must continue where the reference's jitchol continues.
+    Coincident inputs make R = K - V^T V singular to rounding; the protocol function has to come back with a usable
+    factor (C C^T = R up to the jitter it added) instead of raising on the first non-positive pivot."""
+    from oracle.kcgp_ref import covK as ocov
+    rng = np.random.RandomState(4)
+    n = 80
+    x = np.repeat(rng.uniform(0, 10, (n // 2, 1)), 2, axis=0)
+    K = ocov.RBF(np.log(1.0), np.log(10.0)).getCovMatrix(x=x, mode='train')
+    f, g_in, sn = rng.standard_normal(n), rng.standard_normal(n) * 3., 1.2
+    g, K_S, m, C, L = gp['sliceSample'].aux_var_model(f, K, sn, g=g_in)
+    Cn, Ln = C.cpu().numpy(), L.cpu().numpy()
+    np.testing.assert_allclose(Ln @ Ln.T, K_S.cpu().numpy(), rtol=0, atol=1e-9 * 100)
+    S = sn ** 2
+    R = K - K @ np.linalg.solve(K + S * np.eye(n), K)
+    np.testing.assert_allclose(Cn @ Cn.T, R, rtol=0, atol=1e-5)          # jitter <= mean(diag R) * 1e-5 at worst
+    np.testing.assert_allclose(m.cpu().numpy(), R @ (g_in / S), rtol=0, atol=1e-6 * np.abs(g_in).max())
+
+
+def test_numpy_return_mode_runs_the_literal_sampler_over_the_device_kcGP(golden_dir, gp):
+    """The drop-in UNDER the existing sampler (VERDICT missing #2): with gpmc.set_return('numpy') the kcGP mirrors return
+    fresh ndarrays, so sliceSample.py-shaped NumPy code -- here the oracle's LITERAL restatement of
+    sliceSample.py:76-207 (np.diagonal(K), np.linalg.solve(L, K), np.linalg.inv ...), standing in for the reference file
+    that cannot travel to the GPU box -- runs on top of gpmc.covK / gpmc.tools unchanged and reproduces the reference's
+    own seeded trace."""
+    gpmc = gp['gpmc']
+    z = _load(golden_dir, 'trace_framework_n64.npz')
+    saved = (sds_ref.covK, sds_ref.tools)
+    try:
+        gpmc.set_return('numpy')
+        sds_ref.covK, sds_ref.tools = gp['covK'], gp['tools']
+        K = gp['covK'].RBF(0.0, 0.0).getCovMatrix(x=z['x'], mode='train')
+        assert isinstance(K, np.ndarray) and isinstance(gp['tools'].jitchol(K + np.eye(K.shape[0])), np.ndarray)
+        np.random.seed(int(z['seed']))
+        histF, histHyp, ntries = sds_ref.run_chain(z['x'], z['y'], int(z['iters']), z['hyp0'], literal=True)
+        tail = np.random.uniform(size=4)
+    finally:
+        sds_ref.covK, sds_ref.tools = saved
+        gpmc.set_return('torch')
+    np.testing.assert_array_equal(ntries, z['ntries'])
+    np.testing.assert_allclose(histHyp, z['histHyp'], rtol=1e-10)
     np.testing.assert_array_equal(tail, z['rng_tail'])
     np.testing.assert_allclose(histF, z['histF'], rtol=0, atol=5e-2)
 

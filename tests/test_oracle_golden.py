@@ -78,6 +78,22 @@ def test_seeded_trace_literal(golden_dir, name):
     np.testing.assert_array_equal(tail, z['rng_tail'])
 
 
+@pytest.mark.parametrize('name', ['trace_demo_n200.npz', 'trace_demo_n455.npz'])
+def test_seeded_trace_literal_at_the_reference_sizes(golden_dir, name):
+    """the reference's own demo sizes (demoRegression.py:118-131 generator; 30 / 20 iterations): the literal
+    restatement reproduces the reference run draw for draw, and the decision margins stored with the fixture"""
+    z = _load(golden_dir, name)
+    np.random.seed(int(z['seed']))
+    marg = []
+    histF, histHyp, ntries = sds_ref.run_chain(z['x'], z['y'], int(z['iters']), z['hyp0'], literal=True, margins=marg)
+    tail = np.random.uniform(size=4)
+    np.testing.assert_array_equal(ntries, z['ntries'])
+    np.testing.assert_allclose(histHyp, z['histHyp'], rtol=1e-13)
+    np.testing.assert_array_equal(tail, z['rng_tail'])
+    for i, row in enumerate(marg):
+        np.testing.assert_allclose(row, z['oracle_margins'][i][:len(row)], rtol=1e-9, atol=1e-9)
+
+
 def test_seeded_trace_lean_follows_reference(golden_dir):
     """The lean (triangular) form takes the same accept/reject decisions on a short trace.
 
