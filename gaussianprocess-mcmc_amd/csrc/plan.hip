@@ -133,8 +133,15 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "lookahead")) g_opt.lookahead = value < 0 ? -1 : (value ? 1 : 0);
     else if (!strcmp(name, "use_graph")) g_opt.use_graph = value ? 1 : 0;
     else if (!strcmp(name, "small_tile_m")) g_opt.small_tile_m = value;
+#ifdef GPMC_EXPERIMENTS
     else if (!strcmp(name, "diag_impl")) g_opt.diag_impl = value;
     else if (!strcmp(name, "panel_impl")) g_opt.panel_impl = value;
+    else if (!strcmp(name, "gemm_persistent")) g_opt.gemm_persistent = value;
+#else
+    else if (!strcmp(name, "diag_impl")) { if (value != 0 && value != 3) return fail(-2, "diag_impl %d needs a `make EXPERIMENTS=1` build", value); g_opt.diag_impl = value; }
+    else if (!strcmp(name, "panel_impl")) { if (value != 0 && value != 1) return fail(-2, "panel_impl %d needs a `make EXPERIMENTS=1` build", value); g_opt.panel_impl = value; }
+    else if (!strcmp(name, "gemm_persistent")) { if (value) return fail(-2, "gemm_persistent needs a `make EXPERIMENTS=1` build"); g_opt.gemm_persistent = 0; }
+#endif
     else if (!strcmp(name, "gemm_impl")) g_opt.gemm_impl = value;
     else if (!strcmp(name, "gemm_desync")) g_opt.gemm_desync = value;
     else if (!strcmp(name, "gemm_xcd_map")) g_opt.gemm_xcd_map = value;
@@ -150,7 +157,6 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_8wave")) g_opt.gemm_8wave = value;
     else if (!strcmp(name, "f32_nb")) g_opt.f32_nb = value;
     else if (!strcmp(name, "gemm_small_bk32")) g_opt.gemm_small_bk32 = value;
-    else if (!strcmp(name, "gemm_persistent")) g_opt.gemm_persistent = value;
     else if (!strcmp(name, "replay_form")) g_opt.replay_form = value ? 1 : 0;
     else if (!strcmp(name, "la_dag")) g_opt.la_dag = value ? 1 : 0;
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
@@ -184,6 +190,11 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "gemm_small_bk32")) return g_opt.gemm_small_bk32;
     if (!strcmp(name, "gemm_persistent")) return g_opt.gemm_persistent;
     if (!strcmp(name, "replay_form")) return g_opt.replay_form;
+#ifdef GPMC_EXPERIMENTS
+    if (!strcmp(name, "experiments")) return 1;
+#else
+    if (!strcmp(name, "experiments")) return 0;
+#endif
     if (!strcmp(name, "la_dag")) return g_opt.la_dag;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "dag_workers")) return g_opt.dag_workers;

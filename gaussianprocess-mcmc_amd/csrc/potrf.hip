@@ -20,15 +20,21 @@
 #include <vector>
 
 #include "gpmc_common.h"
-#include "diag_wave.h"
-#include "diag_rb.h"
 #include "diag_mp.h"
 #include "panel_fused.h"
-#include "panel_fused2.h"
 #include "panel_pair.h"
 #include "gemm4.h"
-#include "gemm4p.h"
 #include "tail.h"
+// Superseded variants, kept for the measurements that led to the defaults: single-wave and
+// register-blocked diagonal factors, the 5-wave panel kernel with in-block look-ahead, the persistent GEMM with C
+// prefetch.  `make EXPERIMENTS=1` compiles them in; the default library does not carry them and their options
+// (diag_impl 1/2, panel_impl 2, gemm_persistent) are rejected by gpmc_set_option.
+#ifdef GPMC_EXPERIMENTS
+#include "diag_wave.h"
+#include "diag_rb.h"
+#include "panel_fused2.h"
+#include "gemm4p.h"
+#endif
 
 namespace gpmc {
 
@@ -319,6 +325,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     const size_t smem = (size_t)2 * (BM + BN) * GM_ROWB;
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
+#ifdef GPMC_EXPERIMENTS
             if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && lds_pad == 0 && nblk >= 64) {
                 // persistent pipelined kernel: one 512-thread workgroup per CU walks the tile list, next C tile
                 // prefetched under the current K loop
@@ -335,6 +342,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
+#endif
             if (BM == 128 && lds_pad > 0 && g_opt.gemm_8wave) {
                 // look-ahead phase: one workgroup per CU -> make it 8 waves (2 per SIMD), wave tile 32 x 64
                 auto k8 = gemm4_nt_kernel<4, 2, 8, 4, EPI>;
@@ -349,7 +357,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
-            if (BM == 64 && g_opt.gemm_small_bk32 && K % 32 == 0) {   // small tiles: BK = 32 (half the stages)
+            if constexpr (BM == 64) if (g_opt.gemm_small_bk32 && K % 32 == 0) {   // small tiles: BK = 32 (half the stages)
                 auto ks = gemm4_nt_kernel<WGM, WGN, 4 * TM, TN, EPI, 4>;
                 const size_t smems = (size_t)2 * (BM + BN) * (64 * 4 + 16);
                 static bool attrs_done = false;
@@ -476,6 +484,7 @@ struct Parked {
 template <typename T>
 static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T* dinv, double* lpark, hipStream_t s,
                         Parked& pk, double* lpark21, bool beside_gemm) {
+#ifdef GPMC_EXPERIMENTS
     if (g_opt.panel_impl == 2) {   // fused kernel with in-block look-ahead: 5 waves, wave 4 = serial micro-panel factor
         static bool attr2_done = false;   // per T instantiation
         if (!attr2_done) {
@@ -490,6 +499,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
         }
         return 0;
     }
+#endif
     if (g_opt.panel_impl == 1) {   // fused update + factor + TRSM, one launch per 64 columns (f64 arithmetic; W may be f32)
         static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
@@ -537,15 +547,19 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
             if (rc) return rc;
         }
         T* Wd = W + (size_t)c0 * ld + c0;
-        if (g_opt.diag_impl == 0)
+        if (g_opt.diag_impl == 0 || (sizeof(T) != 8 && g_opt.diag_impl == 3))
             hipLaunchKernelGGL((diag_factor_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
+#ifdef GPMC_EXPERIMENTS
         else if (g_opt.diag_impl == 1)
             hipLaunchKernelGGL((diag_factor_wave_kernel<T>), dim3(1), dim3(64), 0, s, Wd, ld, dinv, info_dev, c0);
-        else if (g_opt.diag_impl == 2 || sizeof(T) != 8)
+        else if (g_opt.diag_impl == 2)
             hipLaunchKernelGGL((diag_factor_rb_kernel<T>), dim3(1), dim3(256), 0, s, Wd, ld, dinv, info_dev, c0);
-        else
+#endif
+        else if constexpr (sizeof(T) == 8)
             hipLaunchKernelGGL(diag_factor_mp_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<double*>(Wd), ld,
                                reinterpret_cast<double*>(dinv), info_dev, c0);
+        else
+            return fail(-1, "potrf: diag_impl %d is not available for this element type", g_opt.diag_impl);
         GPMC_LAUNCH_CHECK();
         const int below = mp - c0 - NB_IN;
         if (below > 0) {
@@ -584,7 +598,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (g_opt.panel_impl == 1 && pk.d0 < 0 && pk.d1 < 0 && pk.l21 < 0) return 0;   // nothing parked
         if (g_opt.panel_impl == 1) {   // whatever the last launch parked: one or two diagonal factors and L21
             hipLaunchKernelGGL((panel_flush3_kernel<T>), dim3(3), dim3(256), 0, s, W, ldw, lpark, lpark21, pk.d0, pk.d1, pk.l21);
-        } else {
+        } else {   // panel_impl 2 (experiments build)
             hipLaunchKernelGGL((panel_flush_kernel<T>), dim3(1), dim3(256), 0, s, W, ldw, lpark, np_ - NB_IN);
         }
         GPMC_LAUNCH_CHECK();
@@ -933,6 +947,7 @@ int gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double* C, i
 // diagnostic: run the DBG instantiation of the panel kernel once on (W, k0, c0) and return 8 s_memtime stamps
 int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, double* lpark,
                        unsigned long long* dbg_dev, hipStream_t s) {
+#ifdef GPMC_EXPERIMENTS
     if (g_opt.panel_impl == 2) {
         GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block2_kernel<true, double>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Panel2Shared)));
@@ -941,6 +956,7 @@ int debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev,
         GPMC_LAUNCH_CHECK();
         return 0;
     }
+#endif
     GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_block_kernel<true, double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PanelShared)));
     hipLaunchKernelGGL((panel_block_kernel<true, double>), dim3((mp - c0) / NB_IN), dim3(256), sizeof(PanelShared), s, W,

@@ -33,6 +33,16 @@ def build(force=False):
     return LIB_PATH
 
 
+ASAN_LIB_PATH = os.path.join(_HERE, 'libgpmc_asan.so')
+
+
+def build_sanitized():
+    """Host-side AddressSanitizer + UBSan build of the same sources (device code uninstrumented) for the no-GPU ABI
+    tests: ``make SANITIZE=1`` -> libgpmc_asan.so.  Never loaded by the product path."""
+    subprocess.check_call(['make', '-C', CSRC, 'SANITIZE=1', '-j4'])
+    return ASAN_LIB_PATH
+
+
 def _sig(lib):
     P, I = c_void_p, c_int
     kb = [I, P, I, I, I, P, I, I, P, P, I, I, I, I, P]

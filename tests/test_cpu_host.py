@@ -37,6 +37,50 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.gpmc_potrf_f64(None, 128, 128, 128, None, None, None) < 0
 
 
+def test_abi_under_host_sanitizers():
+    """the host side of the library under AddressSanitizer + UBSan (``make SANITIZE=1``; GPU
+    sanitizers are not available on this pool).  Every entry point that needs no device is driven in a child process
+    with the ASan runtime preloaded: version / sizes, the option table (good, bad and unknown names, i.e. the
+    vsnprintf error paths), argument validation of every factorisation / plan entry point, gpmc_last_error."""
+    from gpmc import _lib
+    if not os.path.exists(_lib.ASAN_LIB_PATH):
+        _lib.build_sanitized()
+    import glob
+    rt = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    if not rt:
+        pytest.skip('ASan runtime not found')
+    script = r"""
+import ctypes, sys
+L = ctypes.CDLL(sys.argv[1])
+L.gpmc_last_error.restype = ctypes.c_char_p
+L.gpmc_potrf_scratch_bytes.restype = ctypes.c_size_t
+L.gpmc_plan_workspace_bytes.restype = ctypes.c_size_t
+assert L.gpmc_version() == 100 and L.gpmc_pad(200) == 256 and L.gpmc_pad(8192) == 8192
+assert L.gpmc_potrf_scratch_bytes(8192) > 2 << 20
+assert L.gpmc_plan_workspace_bytes(8192, 2, 8) > 8192 * 8192 * 8 and L.gpmc_plan_workspace_bytes(0, 2, 8) == 0
+for name in (b'outer_nb', b'lookahead', b'tail_m', b'dag_workers', b'tail_workers', b'la_dag', b'replay_form', b'use_graph'):
+    v = L.gpmc_get_option(name); assert L.gpmc_set_option(name, v) == 0, name
+assert L.gpmc_set_option(b'outer_nb', 100) != 0 and b'multiple of 128' in L.gpmc_last_error()
+assert L.gpmc_set_option(b'tail_m', 100) != 0 and L.gpmc_set_option(b'no_such_option_' + b'x' * 600, 1) != 0
+assert L.gpmc_set_option(None, 1) != 0 and L.gpmc_get_option(None) == -1 and L.gpmc_get_option(b'nope') == -1
+P = ctypes.c_void_p
+assert L.gpmc_potrf_f64(None, 256, 256, 256, None, None, None) < 0 and b'bad argument' in L.gpmc_last_error()
+assert L.gpmc_potrf_tri_f64(None, 256, 256, 256, 128, None, None, None) < 0
+assert L.gpmc_kbuild_f64(0, None, 0, 0, 0, None, 0, 0, None, None, 0, 0, 0, 0, None) != 0
+assert L.gpmc_syrk_tri_f64(None, 0, ctypes.c_double(0.), None, 0, 0, 0, None) < 0
+assert L.gpmc_trsm_rows_f64(None, 0, 0, None, 0, 0, None) < 0 and L.gpmc_gemm_nt_f64(None, 0, None, 0, None, 0, 0, 0, 0, None) < 0
+h = P()
+assert L.gpmc_plan_create(ctypes.byref(h), 7, 10, 2, 8, None, 0, None) < 0      # bad kernel id
+assert L.gpmc_plan_create(ctypes.byref(h), 0, 10, 99, 8, None, 0, None) < 0     # d too large
+assert L.gpmc_plan_create(None, 0, 10, 2, 8, None, 0, None) < 0
+assert L.gpmc_plan_destroy(None) == 0 and L.gpmc_profile_read(None) != 0
+print('sanitized ABI ok')
+"""
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', UBSAN_OPTIONS='halt_on_error=1')
+    out = subprocess.run([sys.executable, '-c', script, _lib.ASAN_LIB_PATH], env=env, capture_output=True, timeout=240)
+    assert out.returncode == 0 and b'sanitized ABI ok' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
 def test_product_path_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -227,22 +227,31 @@ def test_panel_and_gemm_variants_agree(gp):
     gpmc = gp['gpmc']
     ref = sds_ref.gp_log_marginal(x, g, hyp)
     vals = {}
+    variants = [('tile-DAG (default)', {}), ('launch chain', {'tail_m': 0}), ('three-kernel', {'tail_m': 0, 'panel_impl': 0}),
+                ('three-kernel, LDS column-loop diagonal factor', {'tail_m': 0, 'panel_impl': 0, 'diag_impl': 0}),
+                ('gemm16', {'tail_m': 0, 'gemm_impl': 0})]
+    if gpmc.get_option('experiments'):          # `make EXPERIMENTS=1` builds only
+        variants += [('panel2', {'tail_m': 0, 'panel_impl': 2}), ('diag_wave', {'tail_m': 0, 'panel_impl': 0, 'diag_impl': 1}),
+                     ('diag_rb', {'tail_m': 0, 'panel_impl': 0, 'diag_impl': 2})]
+
+    def reset():
+        for k, v in (('panel_impl', 1), ('gemm_impl', 1), ('diag_impl', 3), ('tail_m', 4096)):
+            gpmc.set_option(k, v)
     try:
-        for name, opts in (('default', {}), ('panel2', {'panel_impl': 2}), ('three-kernel', {'panel_impl': 0}),
-                           ('gemm16', {'gemm_impl': 0}), ('diag_wave', {'panel_impl': 0, 'diag_impl': 1}),
-                           ('diag_rb', {'panel_impl': 0, 'diag_impl': 2})):
+        for name, opts in variants:
             for k, v in opts.items():
                 gpmc.set_option(k, v)
             vals[name] = gp['core'].log_marginal(x, g, hyp)
-            gpmc.set_option('panel_impl', 1), gpmc.set_option('gemm_impl', 1), gpmc.set_option('diag_impl', 3)
+            reset()
     finally:
-        gpmc.set_option('panel_impl', 1), gpmc.set_option('gemm_impl', 1), gpmc.set_option('diag_impl', 3)
+        reset()
     for name, v in vals.items():
         assert abs(v - ref) <= 1e-10 * abs(ref), (name, v, ref)
 
 
 def test_large_size_schedule_options_agree(gp):
-    """Options that only take effect with big tiles / look-ahead (N = 4096, look-ahead forced from the start):
+    """Options of round 1's launch-chain schedule (tail_m = 0, la_dag = 0: what f32 storage still runs), which only take
+    effect with big tiles / look-ahead (N = 4096, look-ahead forced from the start):
     schedule-only ones (depth-2 look-ahead, enqueue order, panel priority, LDS pad = CU sharing, XCD tile order) must
     reproduce the default's bits; alternative GEMM kernels (persistent, 8-wave, BK=32 small tiles) the same value to
     rounding.  All within 1e-10 of SciPy."""
@@ -250,14 +259,17 @@ def test_large_size_schedule_options_agree(gp):
     x, g = _x(n, 2, 5), np.random.RandomState(6).standard_normal(n) * 5.
     hyp = [1.2, 9.0, 1.1]
     gpmc = gp['gpmc']
-    base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024}
+    base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024, 'tail_m': 0, 'la_dag': 0}
     reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 2048, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
-             'panel_prio': 0, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_persistent': 0, 'gemm_8wave': 0,
-             'gemm_small_bk32': 0}
-    variants = (('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('prio', {'panel_prio': 1}),
+             'panel_prio': 1, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_8wave': 0,
+             'gemm_small_bk32': 0, 'tail_m': 4096, 'la_dag': 1, 'la_min_np': 4096}
+    variants = [('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('noprio', {'panel_prio': 0}),
                 ('share_cu', {'gemm_lds_pad': 9216, 'panel_prio': 1}), ('xcd_map', {'gemm_xcd_map': 1}),
-                ('persistent', {'lookahead': 0, 'gemm_persistent': 1}), ('eight_wave', {'gemm_8wave': 1}),
-                ('bk32', {'gemm_small_bk32': 1}))
+                ('eight_wave', {'gemm_8wave': 1}), ('bk32', {'gemm_small_bk32': 1}),
+                ('dag look-ahead + tile-DAG tail', {'tail_m': 4096, 'la_dag': 1, 'la_min_np': 1024, 'outer_nb': 256})]
+    if gpmc.get_option('experiments'):
+        variants.append(('persistent', {'lookahead': 0, 'gemm_persistent': 1}))
+        reset['gemm_persistent'] = 0
     vals = {}
     try:
         for name, opts in variants:
@@ -273,7 +285,7 @@ def test_large_size_schedule_options_agree(gp):
     for name, v in vals.items():
         assert v[0] == v[1], name
         assert abs(v[0] - ref) <= 1e-10 * abs(ref), (name, v[0], ref)
-    for name in ('depth2', 'order1', 'prio', 'share_cu', 'xcd_map'):
+    for name in ('depth2', 'order1', 'noprio', 'share_cu', 'xcd_map'):
         assert vals[name][0] == vals['default'][0], name
 
 
