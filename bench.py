@@ -435,8 +435,9 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (no GPU work; plumbing test only)',
             'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
                        'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
-                       'schedule': 'auto (look-ahead NB=256 while >2048 columns remain, then serial NB=128)',
-                       'launch': 'recorded sequence of linear hipGraphs, replayed',
+                       'schedule': 'auto (look-ahead: one tile-DAG launch per 256-column panel beside the trailing GEMM while '
+                                   '>4096 columns remain, then one tile-DAG launch for the rest)',
+                       'launch': 'recorded launch sequence (one fork/join hipGraph), replayed',
                        'enqueue': 'pipelined (back to back)' if a.pipelined else 'sync-each (result read before the next step)',
                        'g': 'GP draw chol(K+sn^2 I) z at the truth hyper-parameters (BASELINE.md 2)'},
             'roofline': {'bound': 'mfma', 'kernel': 'gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)',

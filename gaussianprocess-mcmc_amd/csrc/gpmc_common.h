@@ -57,6 +57,8 @@ struct Options {
     int tail_workers = 448;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
+    int dag_hist = 1;         // look-ahead panels: 1 = the tile-DAG launch accumulates the previous panel's update itself,
+                              // 0 = a GEMM launch on the panel stream does it first
     int la_dag = 1;           // f64 look-ahead: factor every outer panel with one tile-DAG launch (potrf.hip), 0: round 1's
                               // next-panel update + per-64/128-column panel launches
     int use_graph = 1;        // record the plan's launch sequence once and replay it

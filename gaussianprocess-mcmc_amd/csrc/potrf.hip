@@ -753,7 +753,13 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             const int k2 = k1 + nbn;
             if (ge) rc = sc->edge_wait(ps, ge);
             if (rc) return rc;
-            rc = dag_launch(k1, nbn / NB_IN, mp, nbk / NB_IN, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2);
+            int hist = nbk / NB_IN;
+            if (!g_opt.dag_hist) {   // experiment: panel k's update of the next panel's columns by the GEMM kernel instead
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, ps, k1, k2, true, pad_la);
+                if (rc) return rc;
+                hist = 0;
+            }
+            rc = dag_launch(k1, nbn / NB_IN, mp, hist, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2);
             if (rc) return rc;
             hipEvent_t pe_next;
             rc = sc->edge_record(ps, &pe_next);

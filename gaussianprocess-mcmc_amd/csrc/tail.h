@@ -317,7 +317,9 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
 #pragma unroll
             for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = X[g];
             __syncthreads();
+            TAIL_STAMP(9);
             tail_tile_out(tile(xi, xl), ld, sh.Ls, tid);       // stores in flight ...
+            TAIL_STAMP(10);
             if (pair) {
                 // ... while (tl,tl) takes the update by its own column tl-1 straight from LDS
 #pragma unroll 2
