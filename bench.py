@@ -422,6 +422,13 @@ def main():
     if rank == 0:
         value = world * a.steps / tmax
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 else 0.0
+        roof_kernel = 'gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)'
+        if k_launches == 0 and not stub:
+            # problems of <= 4096 columns are ONE tile-DAG launch (csrc/tail.h): no trailing-update launches exist, the
+            # factorisation kernel itself is the dominant kernel and its launch is the step
+            roof_kernel = 'gpmc::tail_kernel (the whole factorisation as one tile-DAG launch; latency-bound pivot chain)'
+            achieved = (a.n ** 3 / 3.0) / (tmax / a.steps) / 1e12
+            k_launches, k_ms, k_flops = a.steps, 1e3 * tmax, a.steps * a.n ** 3 / 3.0
         traffic, traffic_src = pmc_traffic(a.n) if (a.d == 2 and not stub) else (None, None)
         other = 'pipelined' if not a.pipelined else 'sync_each'
         extra[other + '_evals_per_s'] = a.steps / dt_other          # this rank's own rate in the other enqueue form
@@ -440,7 +447,7 @@ def main():
                        'launch': 'recorded launch sequence (one fork/join hipGraph), replayed',
                        'enqueue': 'pipelined (back to back)' if a.pipelined else 'sync-each (result read before the next step)',
                        'g': 'GP draw chol(K+sn^2 I) z at the truth hyper-parameters (BASELINE.md 2)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)',
+            'roofline': {'bound': 'mfma', 'kernel': roof_kernel,
                          'achieved': achieved, 'peak': FP64_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MATRIX_PEAK_TF,
                          'launches_per_step': k_launches / max(a.steps, 1),
