@@ -57,6 +57,9 @@ struct Options {
     int tail_workers = 448;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
+    int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the
+                              // timeout path -- every wait that is not already satisfied aborts the launch)
+    int dag_wprio = 0;        // wave priority (0-2) of the worker workgroups of a look-ahead panel launch (the pairs run at 3)
     int dag_hist = 1;         // look-ahead panels: 1 = the tile-DAG launch accumulates the previous panel's update itself,
                               // 0 = a GEMM launch on the panel stream does it first
     int la_dag = 1;           // f64 look-ahead: factor every outer panel with one tile-DAG launch (potrf.hip), 0: round 1's

@@ -160,6 +160,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "replay_form")) g_opt.replay_form = value ? 1 : 0;
     else if (!strcmp(name, "la_dag")) g_opt.la_dag = value ? 1 : 0;
     else if (!strcmp(name, "dag_hist")) g_opt.dag_hist = value ? 1 : 0;
+    else if (!strcmp(name, "tail_spin_limit")) g_opt.tail_spin_limit = value < 0 ? 0 : value;
+    else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
     else if (!strcmp(name, "dag_workers")) g_opt.dag_workers = value < 0 ? 0 : value;
     else if (!strcmp(name, "tail_m")) { if (value < 0 || value > 4096 || value % 64) return fail(-2, "tail_m must be a multiple of 64 in [0, 4096]"); g_opt.tail_m = value; }
@@ -198,6 +200,8 @@ int gpmc_get_option(const char* name) {
 #endif
     if (!strcmp(name, "la_dag")) return g_opt.la_dag;
     if (!strcmp(name, "dag_hist")) return g_opt.dag_hist;
+    if (!strcmp(name, "tail_spin_limit")) return g_opt.tail_spin_limit;
+    if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "dag_workers")) return g_opt.dag_workers;
     if (!strcmp(name, "tail_m")) return g_opt.tail_m;

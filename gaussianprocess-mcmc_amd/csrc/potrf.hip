@@ -661,7 +661,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int grid = Tt + (ntl < workers ? ntl : workers);
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), sizeof(TailShared), st,
                            reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
-                           g_tail_dbg);
+                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit);
         GPMC_LAUNCH_CHECK();
         return 0;
     };

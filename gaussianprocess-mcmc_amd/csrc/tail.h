@@ -42,7 +42,7 @@ constexpr int TAIL_MAXT = 64;                   // block columns of one launch
 // sync words of one launch: [0] abort word (16-byte slot), then flag[col][row], row stride R
 __host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
-constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // polls before giving up (~1 s)
+constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // default number of polls before giving up (~1 s)
 constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
 
 struct TailShared {
@@ -94,14 +94,15 @@ __device__ inline void tail_tile_out(double* __restrict__ dst, int ld, const dou
 __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
-__device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsigned* abortw, TailShared& sh, int tid) {
+__device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsigned* abortw, TailShared& sh, int tid,
+                                  unsigned spin_limit) {
     if (tid == 0) {
         int ok = 1;
         for (unsigned spins = 0;; ++spins) {
             const unsigned a = tail_ld32(f1), b = tail_ld32(f2);
             if (a != 0u && b != 0u) break;
             if ((spins & 255u) == 255u && tail_ld32(abortw) != 0u) { ok = 0; break; }
-            if (spins > TAIL_SPIN_LIMIT) {
+            if (spins >= spin_limit) {
                 __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -131,7 +132,7 @@ __host__ __device__ inline int tail_tiles(int T, int R) {
 
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
-            int* __restrict__ info, unsigned long long* __restrict__ dbg) {
+            int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
@@ -150,6 +151,8 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     auto zero_tile = [&](int ti_, int col) { return ti_ >= tri0 && col + gb < ti_ - tri0; };
     const bool pair = (int)blockIdx.x < T;        // pair of column blockIdx.x: owns (tl,tl) and, for tl >= 1, (tl,tl-1)
     if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
+    else if (wprio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (wprio == 2) __builtin_amdgcn_s_setprio(2);
     const int ntiles = tail_tiles(T, R);
     unsigned* const ticketw = sync + 1;
     bool alive = true;
@@ -268,7 +271,7 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     }
     for (int col = 0; col < xl && alive; ++col) {
         if (zero_tile(xi, col)) continue;
-        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid);
+        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
         if (!alive) break;
         accumulate(col);
     }
@@ -276,7 +279,7 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
     TAIL_STAMP(1);
     if (alive && xl >= 0) {
-        alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid);
+        alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid, spin_limit);
         TAIL_STAMP(2);
         if (alive) {
             tail_tile_in(Lout, tile(xl, xl), ld, tid);

@@ -516,3 +516,36 @@ def test_slot_rearm_in_flight_is_rejected(gp):
     b = plan.result(5)[0]
     assert a == plan([1.0, 10.0, 1.2]) and b == plan([2.0, 8.0, 1.0])
     plan.close()
+
+
+def test_tile_dag_bounded_spins_drain_the_grid_and_surface_as_an_error(gp):
+    """Safety property of the tile-DAG kernel (csrc/tail.h): every spin is bounded, a workgroup that gives up raises the
+    abort word, all others leave, the grid drains and *info = -1001, which the mirrors report as GpmcError -- never as
+    "not positive definite" (no jitter retry), never as a hang.  Forced here with a spin budget of zero polls: every
+    wait that is not already satisfied aborts the launch.  Afterwards, with the default budget, the same plan object
+    evaluates correctly again (sync words are re-zeroed per factorisation)."""
+    from gpmc import _lib
+    gpmc = gp['gpmc']
+    n = 2048
+    x, g = _x(n, 2, 41), np.random.RandomState(42).standard_normal(n) * 5.
+    hyp = [1.0, 10.0, 1.2]
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    good = plan(hyp)
+    try:
+        gpmc.set_option('use_graph', 0)
+        gpmc.set_option('tail_spin_limit', 0)
+        p2 = gp['core'].LogMarginalPlan(x, g, 'rbf')
+        with pytest.raises(_lib.GpmcError, match='timed out'):
+            p2(hyp)
+        torch.cuda.synchronize()                       # the aborted launch has drained
+        gpmc.set_option('tail_spin_limit', 1 << 20)
+        assert p2(hyp) == good
+        p2.close()
+        with pytest.raises(_lib.GpmcError, match='timed out'):
+            gpmc.set_option('tail_spin_limit', 0)
+            gp['tools'].jitchol(_spd(300, 1))
+    finally:
+        gpmc.set_option('tail_spin_limit', 1 << 20)
+        gpmc.set_option('use_graph', 1)
+    assert plan(hyp) == good
+    plan.close()
