@@ -22,7 +22,7 @@ template <int WGM, int WGN, int RG, int CG, bool EPI, int KCH = 2>
 __global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
-                double diag_add, int g_desync, int xmap, int ktri) {
+                double diag_add, int g_desync, int xmap, int ktri, int prio_cols, unsigned* __restrict__ gflag) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
     constexpr int BKE = 8 * KCH;                           // k elements per stage
@@ -34,6 +34,8 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     char* Bs = smem4 + 2 * BM * ROWB;       // [2][BN][ROWB]
 
     int ti, tj;
+    bool is_prio = false;
+    int prio_slot = 0;
     if (xmap) {
         // XCD-aware order (workgroups b and b+8 share an XCD and its private 4 MB L2): every XCD walks 8x8
         // super-blocks of tiles, so its ~64 resident workgroups touch 8 A-tiles + 8 B-tiles (2 MB, each reused
@@ -64,6 +66,40 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
         ti = 8 * I + r;
         tj = 8 * J + cc;
         if (ti >= xmap || tj >= ntc || (tri && tj > ti)) return;   // xmap carries mt (tile rows)
+    } else if (tri && prio_cols > 0) {
+        // Look-ahead hand-over inside the launch (potrf.hip, la_dag): the first prio_cols tile columns -- the columns of
+        // the panel after next -- are processed FIRST (blocks are dispatched in index order) and every such tile
+        // publishes a flag when it is in memory, so the tile-DAG launch that factors that panel starts on them while the
+        // rest of this update is still running.  The remaining tiles follow in the usual order on the shifted trapezoid.
+        const int b = blockIdx.x;
+        const int T3 = ntc * (ntc + 1) / 2;
+        const int mt = ntc + ((int)gridDim.x - T3) / ntc;          // tile rows of the whole region
+        int P = 0;
+        for (int j = 0; j < prio_cols; ++j) P += mt - j;
+        if (b < P) {
+            tj = 0;
+            int q = b;
+            while (q >= mt - tj) { q -= mt - tj; ++tj; }
+            ti = tj + q;
+            is_prio = true;
+            prio_slot = tj * mt + ti;
+        } else {
+            const int bb = b - P, n2 = ntc - prio_cols;
+            const int T32 = n2 * (n2 + 1) / 2;
+            int t2, j2;
+            if (bb < T32) {
+                t2 = (int)((sqrt(8.0 * (double)bb + 1.0) - 1.0) * 0.5);
+                while (t2 * (t2 + 1) / 2 > bb) --t2;
+                while ((t2 + 1) * (t2 + 2) / 2 <= bb) ++t2;
+                j2 = bb - t2 * (t2 + 1) / 2;
+            } else {
+                const int b3 = bb - T32;
+                t2 = n2 + b3 / n2;
+                j2 = b3 % n2;
+            }
+            ti = t2 + prio_cols;
+            tj = j2 + prio_cols;
+        }
     } else {
         const int b = blockIdx.x;
         if (tri) {
@@ -199,6 +235,17 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
             if (g_desync & 16) __builtin_nontemporal_store(v, &C[(size_t)gr * ldc + gc]);
             else C[(size_t)gr * ldc + gc] = v;
         }
+    if (is_prio) {
+        // publish: plain stores -> every storing wave drains -> workgroup barrier -> one lane's agent-scope release
+        // (L2 write-back), drained -> relaxed agent flag store (CDNA4 guide, inter-workgroup visibility, valid forms)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(gflag + prio_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace gpmc

@@ -59,6 +59,8 @@ struct Options {
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
     int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the
                               // timeout path -- every wait that is not already satisfied aborts the launch)
+    int dag_ahead = 1;        // look-ahead: the trailing GEMM hands the next-but-one panel's columns over tile by tile inside its
+                              // launch (priority tile columns + flags) instead of at its end
     int dag_wprio = 0;        // wave priority (0-2) of the worker workgroups of a look-ahead panel launch (the pairs run at 3)
     int dag_hist = 1;         // look-ahead panels: 1 = the tile-DAG launch accumulates the previous panel's update itself,
                               // 0 = a GEMM launch on the panel stream does it first

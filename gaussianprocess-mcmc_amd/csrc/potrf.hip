@@ -308,7 +308,7 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, int ldcin, T* C, int ldc, int mrows,
                        int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s,
-                       int ktri = 0, int lds_pad = 0) {
+                       int ktri = 0, int lds_pad = 0, int prio_cols = 0, unsigned* gflag = nullptr) {
     constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
     constexpr int BK = 128 / (int)sizeof(T);
     if (mrows <= 0 || ncols <= 0) return 0;
@@ -326,7 +326,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
     if constexpr (sizeof(T) == 8) {
         if (g_opt.gemm_impl == 1) {   // v_mfma_f64_4x4x4 slabs: same tile sizes, RG = 4 TM row-groups, CG = TN
 #ifdef GPMC_EXPERIMENTS
-            if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && lds_pad == 0 && nblk >= 64) {
+            if (BM == 128 && beta && !ktri && g_opt.gemm_persistent && lds_pad == 0 && nblk >= 64 && !gflag) {
                 // persistent pipelined kernel: one 512-thread workgroup per CU walks the tile list, next C tile
                 // prefetched under the current K loop
                 auto kp = gemm4p_nt_kernel<EPI>;
@@ -343,7 +343,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 return 0;
             }
 #endif
-            if (BM == 128 && lds_pad > 0 && g_opt.gemm_8wave) {
+            if (BM == 128 && lds_pad > 0 && g_opt.gemm_8wave && !gflag) {
                 // look-ahead phase: one workgroup per CU -> make it 8 waves (2 per SIMD), wave tile 32 x 64
                 auto k8 = gemm4_nt_kernel<4, 2, 8, 4, EPI>;
                 static bool attr8_done = false;
@@ -353,7 +353,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attr8_done = true;
                 }
                 hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)lds_pad, s, A, lda, B, ldb, Cin, ldcin,
-                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0, ktri);
+                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0, ktri, 0, (unsigned*)nullptr);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -367,7 +367,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attrs_done = true;
                 }
                 hipLaunchKernelGGL(ks, dim3(nblk), dim3(256), smems, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                                   alpha, beta, n_true, diag_add, 0, 0, ktri);
+                                   alpha, beta, n_true, diag_add, 0, 0, ktri, 0, (unsigned*)nullptr);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -380,14 +380,14 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
             }
             const size_t smem4 = smem + ((BM == 128) ? (size_t)lds_pad : 0);
             int xmap = 0, nblk4 = nblk;
-            if (g_opt.gemm_xcd_map && mt >= 16) {   // super-block order; grid = (#super-blocks rounded to 8) * 64
+            if (g_opt.gemm_xcd_map && mt >= 16 && !gflag) {   // super-block order; grid = (#super-blocks rounded to 8) * 64
                 const int SC = (ntc + 7) / 8, SR = (mt + 7) / 8;
                 const int nsb = tri ? SC * (SC + 1) / 2 + (SR - SC) * SC : SR * SC;
                 nblk4 = ((nsb + 7) / 8 * 8) * 64;
                 xmap = mt;
             }
             hipLaunchKernelGGL(k4, dim3(nblk4), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap, ktri);
+                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap, ktri, gflag ? prio_cols : 0, gflag);
             GPMC_LAUNCH_CHECK();
             return 0;
         }
@@ -449,7 +449,7 @@ int profile_read(double* out) {   // out: [0] total ms in the kernel, [1] launch
 // C(mrows x ncols region) -= A A_j^T, big (128x128) or small (64x64) tiles by problem size
 template <typename T>
 static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipStream_t s, int col_lo, int col_hi,
-                           bool latency_bound = false, int lds_pad = 0) {
+                           bool latency_bound = false, int lds_pad = 0, int prio_cols = 0, unsigned* gflag = nullptr) {
     // update columns [col_lo, col_hi) of the trailing matrix (rows >= col_lo), K = nbk panel at k0
     const int rows = mp - col_lo;
     const int cols = col_hi - col_lo;
@@ -467,7 +467,10 @@ static int trailing_update(T* W, int ld, int k0, int nbk, int mp, int np_, hipSt
     }
     int rc;
     if (rows > g_opt.small_tile_m && !latency_bound)
-        rc = launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s, 0, lds_pad);
+        rc = launch_gemm<T, 2, 2, 4, 4, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s, 0, lds_pad,
+                                               prio_cols, gflag);
+    else if (gflag)
+        return fail(-1, "trailing_update: in-launch hand-over needs the big-tile GEMM");
     else
         rc = launch_gemm<T, 2, 2, 2, 2, false>(P, ld, P, ld, C, ld, C, ld, rows, cols, nbk, 1, (T)-1, 1, 0, (T)0, s);
     if (rc) return rc;
@@ -642,7 +645,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // region is zeroed right here.
     size_t sync_next = 0;
     bool sync_zeroed = false;
-    auto dag_launch = [&](int k0, int Tt, int mp_rows, int Hh, hipStream_t st, int workers) -> int {
+    auto dag_launch = [&](int k0, int Tt, int mp_rows, int Hh, hipStream_t st, int workers,
+                          const unsigned* gflag = nullptr, int gmt = 0) -> int {
         const int Rt = (mp_rows - k0) / NB_IN;
         const size_t words = tail_sync_words(Tt, Rt);
         if (!sync_zeroed) sync_next = 0;
@@ -661,7 +665,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         const int grid = Tt + (ntl < workers ? ntl : workers);
         hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), sizeof(TailShared), st,
                            reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
-                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit);
+                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt);
         GPMC_LAUNCH_CHECK();
         return 0;
     };
@@ -714,6 +718,19 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         hipEvent_t pe, ge = nullptr;
         int nbk = la_nb(np_);
         if (nbk > np_) nbk = np_;
+        // In-launch hand-over (dag_ahead): G_k -- the update of the columns beyond panel k+1 by panel k -- processes the
+        // tiles of panel k+2's columns first and flags each one (gemm4.h), and D_{k+2} gates its tiles on those flags
+        // instead of on G_k's end: the panel chain runs up to a step ahead of the GEMM chain, which then runs back to
+        // back.  Words of G_k's flags: (tile columns of panel k+2) x (tile rows of its region), 0 when not used.
+        auto next_nb = [&](int kk) { return (np_ - kk < la_nb(np_ - kk)) ? np_ - kk : la_nb(np_ - kk); };
+        auto handover_words = [&](int k1, int k2) -> size_t {
+            if (!g_opt.dag_ahead || !g_opt.dag_hist || g_opt.gemm_impl != 1 || k2 >= np_ || hand_over(k2)) return 0;
+            const int rows = mp_at(k1) - k2;
+            if (rows <= g_opt.small_tile_m || rows % 128 || (np_ - k2) % 128) return 0;
+            return (size_t)(next_nb(k2) / 128) * (size_t)(rows / 128);
+        };
+        const unsigned* gf_prev = nullptr;     // hand-over flags the NEXT panel launch gates on (of the last GEMM launched)
+        int gmt_prev = 0;
         {   // sync words of every launch of this schedule, zeroed once, here, on s before the fork
             size_t total = 0;
             for (int k0 = 0, nb = nbk;;) {
@@ -722,6 +739,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (k1 >= np_) break;
                 if (hand_over(k1)) { total += tail_sync_words((np_ - k1) / NB_IN, (mp - k1) / NB_IN); break; }
                 nb = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
+                total += handover_words(k1, k1 + nb);
                 k0 = k1;
             }
             if (total * sizeof(unsigned) <= TAIL_SYNC_BYTES) {
@@ -751,7 +769,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             }
             const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
             const int k2 = k1 + nbn;
-            if (ge) rc = sc->edge_wait(ps, ge);
+            if (ge && gf_prev == nullptr) rc = sc->edge_wait(ps, ge);
             if (rc) return rc;
             int hist = nbk / NB_IN;
             if (!g_opt.dag_hist) {   // experiment: panel k's update of the next panel's columns by the GEMM kernel instead
@@ -759,15 +777,26 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
                 hist = 0;
             }
-            rc = dag_launch(k1, nbn / NB_IN, mp, hist, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2);
+            rc = dag_launch(k1, nbn / NB_IN, mp, hist, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2, gf_prev,
+                            gmt_prev);
             if (rc) return rc;
             hipEvent_t pe_next;
             rc = sc->edge_record(ps, &pe_next);
             if (rc) return rc;
             rc = sc->edge_wait(s, pe);
             if (rc) return rc;
+            gf_prev = nullptr;
             if (k2 < np_) {
-                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_, false, pad_la);
+                const size_t hw = sync_zeroed ? handover_words(k1, k2) : 0;
+                unsigned* gf = nullptr;
+                if (hw) {
+                    gf = dag_sync + sync_next;
+                    sync_next += hw;
+                    gf_prev = gf;
+                    gmt_prev = (mp_at(k1) - k2) / 128;
+                }
+                rc = trailing_update<T>(W, ldw, k0, nbk, mp_at(k1), np_, s, k2, np_, false, pad_la,
+                                        hw ? next_nb(k2) / 128 : 0, gf);
                 if (rc) return rc;
                 rc = sc->edge_record(s, &ge);
                 if (rc) return rc;

@@ -93,6 +93,7 @@ int Sched::end() {
     if (mode == EAGER) return 0;
     const bool forkjoin = (mode == FORKJOIN);
     int rc = 0;
+
     // close what is still open; a failed launch sequence must not leave a stream in capture mode
     for (int k = 0; k < 2; ++k) {
         hipStream_t s = k ? panel : main;

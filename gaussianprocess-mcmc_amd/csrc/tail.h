@@ -94,8 +94,10 @@ __device__ inline void tail_tile_out(double* __restrict__ dst, int ld, const dou
 __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
+// acquire = true: the bytes behind the flags were written with PLAIN stores and released (the GEMM's hand-over tiles):
+// the polling lane follows its poll with an agent-scope acquire (drops this CU's stale L1 lines) before the barrier
 __device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsigned* abortw, TailShared& sh, int tid,
-                                  unsigned spin_limit) {
+                                  unsigned spin_limit, bool acquire = false) {
     if (tid == 0) {
         int ok = 1;
         for (unsigned spins = 0;; ++spins) {
@@ -108,6 +110,10 @@ __device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsign
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
+        }
+        if (acquire) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         sh.ok = ok;
     }
@@ -132,7 +138,8 @@ __host__ __device__ inline int tail_tiles(int T, int R) {
 
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
-            int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit) {
+            int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
+            const unsigned* __restrict__ gflag, int gmt) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
@@ -181,6 +188,17 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     } while (0)
     TAIL_STAMP(0);
 
+    // ---------------- the tile's start values may still be under way: with gflag the trailing update that brings these
+    // columns up to date is RUNNING beside this launch and publishes the 128 x 128 tiles of these columns first
+    // (gemm4.h, prio_cols): wait for the one (pair: the one or two) covering this workgroup's tiles
+    if (gflag != nullptr) {
+        const int ci = pair ? tl : ti, cl0 = pair ? (tl >= 1 ? tl - 1 : tl) : tl;
+        if ((ci >> 1) < gmt) {      // (rows beyond the update's range are untouched by it)
+            alive = tail_wait2(gflag + (cl0 >> 1) * gmt + (ci >> 1), gflag + (tl >> 1) * gmt + (ci >> 1), abortw, sh, tid,
+                               spin_limit, true);
+            if (!alive) break;
+        }
+    }
     // ---------------- tiles into registers
     double D[4][4];     // (tl,tl), slab layout: lane (i, c) of D[m][h] = element [4 (w + 4 m) + i][16 h + c]
     double X[16];       // off-diagonal tile, transposed: lane (i, c) of X[g] = element [16 w + c][4 g + i]

@@ -20,7 +20,14 @@ class LogMarginalPlan(object):
     the log-marginal at fresh hyper-parameters.  The first evaluation launches eagerly, the second records the launch
     sequence (and validates it against the eager time, csrc/plan.hip ``record_sequence``), later ones replay it."""
 
-    def __init__(self, X, g, kernel='rbf', dtype=torch.float64):
+    def __init__(self, X, g, kernel='rbf', dtype=torch.float64, settle=None):
+        """``settle`` (None = auto: on for two-stream schedules, i.e. more than tail_m columns): the fork/join exec of the
+        recorded launch sequence has its branch mapped onto a hardware queue by the runtime; when that is the queue of
+        the plan's own stream -- every 4th stream of torch's pool -- the two chains partly serialise (+12 % at
+        N = 8192; re-instantiating does not move it, another stream does).  Which pool stream a plan
+        gets depends on what else the process created before (RCCL, other plans), so for those sizes the constructor
+        warms the plan up on two consecutive pool streams, times three replays on each and keeps the faster
+        (~60 ms once; the plan is then recorded and validated)."""
         ops.require_gpu()
         self.kernel = kernel
         self.dtype = dtype
@@ -38,7 +45,27 @@ class LogMarginalPlan(object):
         self.workspace = torch.empty(self._nbytes, dtype=torch.uint8, device=self.X.device)  # caller-owned memory
         self._h = None
         self._armed = set()
-        # a stream of its own: the legacy NULL stream torch starts on cannot be graph-captured
+        self._create()
+        if settle is None:
+            settle = bool(_lib.get_option('use_graph')) and _lib.get_option('replay_form') == 1 and \
+                _lib.get_option('lookahead') != 0 and ops.pad(self.n) > max(_lib.get_option('tail_m'), 0) and \
+                ops.pad(self.n) >= _lib.get_option('la_min_np')
+        self.settled = None
+        if settle:
+            t_a = self._warm()
+            keep = (self._stream, self._h)
+            self._create()                                   # the next stream of the pool: another hardware queue
+            t_b = self._warm()
+            self.settled = (t_a, t_b)
+            if t_b < 0.98 * t_a:
+                L.gpmc_plan_destroy(keep[1])
+            else:
+                L.gpmc_plan_destroy(self._h)
+                self._stream, self._h = keep
+
+    def _create(self):
+        """a plan handle on a pool stream of its own (the legacy NULL stream torch starts on cannot be captured)"""
+        L = _lib.lib()
         self._stream = torch.cuda.Stream(device=self.X.device)
         self._stream.wait_stream(torch.cuda.current_stream())
         h = ctypes.c_void_p()
@@ -47,6 +74,25 @@ class LogMarginalPlan(object):
         self._h = h
         _lib.check(L.gpmc_plan_set_data(h, self.X.data_ptr(), self.X.stride(0), self.g.data_ptr()),
                    'gpmc_plan_set_data')
+
+    def _warm(self, reps=3):
+        """two evaluations at neutral parameters [sf2, Sii, ell..] = 1 (K + I is positive definite, the time does not
+        depend on the values) -- the eager one and the one that records the launch sequence -- then the wall time per
+        evaluation of ``reps`` replays, in ms"""
+        import time
+        L = _lib.lib()
+        kp = np.ones(2 + (1 if self.kernel == 'rbf' else self.d), dtype=np.float64)
+        ptr = kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        out = (ctypes.c_double * 4)()
+        for _ in range(2):
+            _lib.check(L.gpmc_plan_logml_async(self._h, ptr, kp.shape[0], 0), 'gpmc_plan_logml_async')
+            _lib.check(L.gpmc_plan_result(self._h, 0, out), 'gpmc_plan_result')
+        t0 = time.perf_counter()
+        for i in range(reps):
+            _lib.check(L.gpmc_plan_logml_async(self._h, ptr, kp.shape[0], i), 'gpmc_plan_logml_async')
+        for i in range(reps):
+            _lib.check(L.gpmc_plan_result(self._h, i, out), 'gpmc_plan_result')
+        return 1e3 * (time.perf_counter() - t0) / reps
 
     def record_info(self):
         """(eager ms, first replay ms, recording attempts, form: 2 fork/join / 1 linear segments / -1 none yet)"""
@@ -121,7 +167,7 @@ class LogMarginalPlan(object):
 
 def log_marginal(X, g, hyp, kernel='rbf', dtype=torch.float64):
     """One-shot convenience: log N(g; 0, K(hyp) + S).  Build a LogMarginalPlan for repeated calls."""
-    plan = LogMarginalPlan(X, g, kernel, dtype)
+    plan = LogMarginalPlan(X, g, kernel, dtype, settle=False)
     try:
         return plan(hyp)
     finally:

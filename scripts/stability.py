@@ -19,5 +19,5 @@ for trial in range(24):
             plan.eval_async(hyps[i % 4], i)
         plan.drain(); torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / 8 * 1e3)
-    print('trial %d: %s ms/eval   (eager ms, first replay ms, recording attempts, form) = %.2f %.2f %d %d' % ((trial, ' '.join('%.2f' % p for p in per)) + plan.record_info()), flush=True)
+    print('trial %d: %s ms/eval   (eager ms, first replay ms, recording attempts, form) = %.2f %.2f %d %d' % ((trial, ' '.join('%.2f' % p for p in per)) + plan.record_info()) + '  candidates (ms) %s' % (None if plan.settled is None else '%.2f / %.2f' % plan.settled,), flush=True)
     plan.close()
