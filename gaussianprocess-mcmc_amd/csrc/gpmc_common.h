@@ -52,9 +52,12 @@ struct Options {
     int panel_lds_pad = 0;    // extra LDS bytes requested by the 64-column panel kernel beside the GEMM; 16384+ makes it wait
                               // for an empty CU instead of sharing one: 8192 6.58 vs 6.41 ms, 16384 33.6 vs 32.8 -> stays 0
     int panel_prio = 1;       // the fused panel kernel raises its wave priority (s_setprio 3): 0-1.5 % under look-ahead, never worse
-    int tail_m = 4096;        // f64: the last <= tail_m columns (a multiple of 64, <= 4096; 0 = never) are factored by the
+    int tail_m = 6144;        // f64: the last <= tail_m columns (a multiple of 64, <= 8192; 0 = never) are factored by the
                               // one-launch tile-DAG kernel (tail.h) instead of the serial NB = 128 launch chain
-    int tail_workers = 448;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
+                              // (N = 8192, ms/eval: 4096 5.20, 5120 5.00, 6144 5.01)
+    int tail_whole_m = 7168;  // problems of at most this many columns are ONE tile-DAG launch (7168: 3.91 ms vs 4.17 with a
+                              // look-ahead phase in front; 8192: 5.57 vs 5.0)
+    int tail_workers = 480;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
     int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the

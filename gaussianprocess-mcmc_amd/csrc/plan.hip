@@ -162,12 +162,13 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "replay_form")) g_opt.replay_form = value ? 1 : 0;
     else if (!strcmp(name, "la_dag")) g_opt.la_dag = value ? 1 : 0;
     else if (!strcmp(name, "dag_hist")) g_opt.dag_hist = value ? 1 : 0;
+    else if (!strcmp(name, "tail_whole_m")) g_opt.tail_whole_m = value < 0 ? 0 : value;
     else if (!strcmp(name, "dag_ahead")) g_opt.dag_ahead = value ? 1 : 0;
     else if (!strcmp(name, "tail_spin_limit")) g_opt.tail_spin_limit = value < 0 ? 0 : value;
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
     else if (!strcmp(name, "dag_workers")) g_opt.dag_workers = value < 0 ? 0 : value;
-    else if (!strcmp(name, "tail_m")) { if (value < 0 || value > 4096 || value % 64) return fail(-2, "tail_m must be a multiple of 64 in [0, 4096]"); g_opt.tail_m = value; }
+    else if (!strcmp(name, "tail_m")) { if (value < 0 || value > 8192 || value % 64) return fail(-2, "tail_m must be a multiple of 64 in [0, 8192]"); g_opt.tail_m = value; }
     else return fail(-1, "gpmc_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -203,6 +204,7 @@ int gpmc_get_option(const char* name) {
 #endif
     if (!strcmp(name, "la_dag")) return g_opt.la_dag;
     if (!strcmp(name, "dag_hist")) return g_opt.dag_hist;
+    if (!strcmp(name, "tail_whole_m")) return g_opt.tail_whole_m;
     if (!strcmp(name, "dag_ahead")) return g_opt.dag_ahead;
     if (!strcmp(name, "tail_spin_limit")) return g_opt.tail_spin_limit;
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;

@@ -635,7 +635,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // the last columns as one tile-DAG launch (tail.h): f64
     const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && fused && g_opt.panel_impl == 1;
     auto use_tail = [&](int k0) {
-        return tail_ok && np_ - k0 <= g_opt.tail_m && (np_ - k0) / NB_IN <= TAIL_MAXT &&
+        return tail_ok && np_ - k0 <= ((k0 == 0 && g_opt.tail_whole_m > g_opt.tail_m) ? g_opt.tail_whole_m : g_opt.tail_m) &&
+               (np_ - k0) / NB_IN <= TAIL_MAXT &&
                tail_sync_words((np_ - k0) / NB_IN, (mp - k0) / NB_IN) * sizeof(unsigned) <= TAIL_SYNC_BYTES;
     };
     unsigned* const dag_sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + potrf_scratch_base(np_));

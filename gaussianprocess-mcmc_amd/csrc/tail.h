@@ -38,7 +38,7 @@
 
 namespace gpmc {
 
-constexpr int TAIL_MAXT = 64;                   // block columns of one launch
+constexpr int TAIL_MAXT = 128;                  // block columns of one launch
 // sync words of one launch: [0] abort word (16-byte slot), then flag[col][row], row stride R
 __host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches

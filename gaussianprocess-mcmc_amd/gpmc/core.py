@@ -48,7 +48,8 @@ class LogMarginalPlan(object):
         self._create()
         if settle is None:
             settle = bool(_lib.get_option('use_graph')) and _lib.get_option('replay_form') == 1 and \
-                _lib.get_option('lookahead') != 0 and ops.pad(self.n) > max(_lib.get_option('tail_m'), 0) and \
+                _lib.get_option('lookahead') != 0 and \
+                ops.pad(self.n) > max(_lib.get_option('tail_m'), _lib.get_option('tail_whole_m'), 0) and \
                 ops.pad(self.n) >= _lib.get_option('la_min_np')
         self.settled = None
         if settle:

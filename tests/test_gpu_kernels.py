@@ -235,7 +235,7 @@ def test_panel_and_gemm_variants_agree(gp):
                      ('diag_rb', {'tail_m': 0, 'panel_impl': 0, 'diag_impl': 2})]
 
     def reset():
-        for k, v in (('panel_impl', 1), ('gemm_impl', 1), ('diag_impl', 3), ('tail_m', 4096)):
+        for k, v in (('panel_impl', 1), ('gemm_impl', 1), ('diag_impl', 3), ('tail_m', 6144)):
             gpmc.set_option(k, v)
     try:
         for name, opts in variants:
@@ -259,14 +259,16 @@ def test_large_size_schedule_options_agree(gp):
     x, g = _x(n, 2, 5), np.random.RandomState(6).standard_normal(n) * 5.
     hyp = [1.2, 9.0, 1.1]
     gpmc = gp['gpmc']
-    base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024, 'tail_m': 0, 'la_dag': 0}
+    base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024, 'tail_m': 0, 'tail_whole_m': 0,
+            'la_dag': 0}
     reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 2048, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
              'panel_prio': 1, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_8wave': 0,
-             'gemm_small_bk32': 0, 'tail_m': 4096, 'la_dag': 1, 'la_min_np': 4096}
+             'gemm_small_bk32': 0, 'tail_m': 6144, 'tail_whole_m': 7168, 'la_dag': 1, 'la_min_np': 4096}
     variants = [('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('noprio', {'panel_prio': 0}),
                 ('share_cu', {'gemm_lds_pad': 9216, 'panel_prio': 1}), ('xcd_map', {'gemm_xcd_map': 1}),
                 ('eight_wave', {'gemm_8wave': 1}), ('bk32', {'gemm_small_bk32': 1}),
-                ('dag look-ahead + tile-DAG tail', {'tail_m': 4096, 'la_dag': 1, 'la_min_np': 1024, 'outer_nb': 256})]
+                ('dag look-ahead + tile-DAG tail', {'tail_m': 2048, 'tail_whole_m': 0, 'la_dag': 1, 'la_min_np': 1024,
+                                                    'outer_nb': 256})]
     if gpmc.get_option('experiments'):
         variants.append(('persistent', {'lookahead': 0, 'gemm_persistent': 1}))
         reset['gemm_persistent'] = 0
@@ -384,7 +386,7 @@ def test_two_live_plans_interleaved(gp):
     stream, events and recorded sequence): interleaved asynchronous evaluations must return each plan's own
     values, bit for bit equal to what the plan computes alone."""
     core = gp['core']
-    xa, ga = _x(6400, 2, 21), np.random.RandomState(22).standard_normal(6400) * 5.
+    xa, ga = _x(7300, 2, 21), np.random.RandomState(22).standard_normal(7300) * 5.
     xb, gb = _x(1500, 2, 23), np.random.RandomState(24).standard_normal(1500) * 5.
     hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [0.7, 12.0, 1.5]]
     pa, pb = core.LogMarginalPlan(xa, ga, 'rbf'), core.LogMarginalPlan(xb, gb, 'rbf')
@@ -404,11 +406,11 @@ def test_two_live_plans_interleaved(gp):
     pb.close()
 
 
-@pytest.mark.parametrize('n,bad', [(6500, 0), (6500, 3000), (6500, 6400), (6500, 6499), (4200, 4100)])
+@pytest.mark.parametrize('n,bad', [(7400, 0), (7400, 1000), (7400, 3000), (7400, 7300), (7400, 7399), (4200, 4100)])
 def test_first_bad_pivot_is_reported_under_lookahead(gp, n, bad):
-    """LAPACK-style info (1-based index of the first non-positive pivot) through the look-ahead schedule (6500), where
-    panels are factored on a second stream, and the serial big-tile schedule (4200); a later, second bad pivot must
-    not overwrite the first."""
+    """LAPACK-style info (1-based index of the first non-positive pivot) through the look-ahead schedule (7400: tile-DAG
+    panels on a second stream, then the tile-DAG tail) and the single tile-DAG launch (4200); a later, second bad pivot
+    must not overwrite the first."""
     ops = gp['ops']
     B = np.random.RandomState(n + 7).standard_normal((n, 32))
     A = B @ B.T + 10. * np.eye(n)                          # SPD, cheap to form
@@ -451,7 +453,7 @@ def _churn(gp, plan, form, devsync, iters):
 @pytest.mark.parametrize('form', [1, 0])
 def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
     """Round 1's abort (VERDICT weak #12): a replayed launch graph destroyed after a device-wide sync, on the look-ahead
-    schedule (n = 4200 -> two streams).  Root cause (profiles/r02_graph_abort_isolation.txt): a use-after-free inside
+    schedule (n = 7300 -> two streams).  Root cause (profiles/r02_graph_abort_isolation.txt): a use-after-free inside
     HIP runtime 7.0.51831 -- the one torch bundles, i.e. the one this test runs on -- when a FORK/JOIN exec is destroyed
     after hipDeviceSynchronize.  form 1 = the default fork/join replay, retired through a launch with every node
     disabled; form 0 = linear graphs cut at the cross-stream edges, plain destroys.  Both must survive record / replay /
@@ -460,7 +462,7 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
     import ctypes
     from gpmc import _lib
     gpmc = gp['gpmc']
-    n = 4200
+    n = 7300
     x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
     hyp = [1.0, 10.0, 1.2]
     try:
@@ -490,7 +492,7 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
 def test_plan_destroy_does_not_touch_the_workspace(gp):
     """gpmc_plan_destroy used to replay the last evaluation into the caller's workspace before destroying the graph
     exec; now it must neither write nor need it: poison the workspace after the last result, destroy, compare."""
-    n = 4200
+    n = 7300
     x, g = _x(n, 2, 33), np.random.RandomState(34).standard_normal(n) * 5.
     plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
     for _ in range(3):
