@@ -287,10 +287,31 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
         if (xl >= 0) accumulate(col);
         else accumulate_D0(col);
     }
+    // A tile's column c+1 needs its column c as an operand, so the published columns of a block row form a prefix:
+    // instead of polling two flags per column (a 1-2 us L2 round trip each time, even when long set), the 64 lanes of
+    // wave 0 look at the next 64 columns of both operand rows at once and the loop runs through everything that is
+    // ready without polling again; it blocks on a single column only when it has caught up with the producers.
+    int ready_upto = 0;
     for (int col = 0; col < xl && alive; ++col) {
         if (zero_tile(xi, col)) continue;
-        alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
-        if (!alive) break;
+        if (col >= ready_upto) {
+            if (tid < 64) {
+                const int cc = col + tid;
+                const bool ok = cc < xl && tail_ld32(flag(cc, xl)) != 0u && tail_ld32(flag(cc, xi)) != 0u;
+                const unsigned long long m = __ballot(ok);
+                if (tid == 0) sh.ok = (int)__builtin_ctzll(~m);           // leading ready columns (0..64)
+            }
+            __syncthreads();
+            const int nready = sh.ok;
+            __syncthreads();
+            if (nready > 0) {
+                ready_upto = col + nready;
+            } else {
+                alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
+                if (!alive) break;
+                ready_upto = col + 1;
+            }
+        }
         accumulate(col);
     }
 
