@@ -163,6 +163,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "la_dag")) g_opt.la_dag = value ? 1 : 0;
     else if (!strcmp(name, "dag_hist")) g_opt.dag_hist = value ? 1 : 0;
     else if (!strcmp(name, "tail_whole_m")) g_opt.tail_whole_m = value < 0 ? 0 : value;
+    else if (!strcmp(name, "tail_m_f32")) { if (value < 0 || value > 8192 || value % 64) return fail(-2, "tail_m_f32 must be a multiple of 64 in [0, 8192]"); g_opt.tail_m_f32 = value; }
+    else if (!strcmp(name, "tail_whole_m_f32")) g_opt.tail_whole_m_f32 = value < 0 ? 0 : value;
     else if (!strcmp(name, "dag_ahead")) g_opt.dag_ahead = value ? 1 : 0;
     else if (!strcmp(name, "tail_spin_limit")) g_opt.tail_spin_limit = value < 0 ? 0 : value;
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -205,6 +207,8 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "la_dag")) return g_opt.la_dag;
     if (!strcmp(name, "dag_hist")) return g_opt.dag_hist;
     if (!strcmp(name, "tail_whole_m")) return g_opt.tail_whole_m;
+    if (!strcmp(name, "tail_m_f32")) return g_opt.tail_m_f32;
+    if (!strcmp(name, "tail_whole_m_f32")) return g_opt.tail_whole_m_f32;
     if (!strcmp(name, "dag_ahead")) return g_opt.dag_ahead;
     if (!strcmp(name, "tail_spin_limit")) return g_opt.tail_spin_limit;
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;

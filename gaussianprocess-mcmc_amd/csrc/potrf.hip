@@ -633,9 +633,13 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
     // the last columns as one tile-DAG launch (tail.h): f64
-    const bool tail_ok = sizeof(T) == 8 && g_opt.tail_m > 0 && fused && g_opt.panel_impl == 1;
+    // (float storage: the kernel converts on load / store, its arithmetic is f64 as in the panel kernels; the f32 trailing
+    // GEMM is twice as fast as the f64 one, so the extents where the launch pays are smaller: tail_m_f32, tail_whole_m_f32)
+    const int tail_m_T = sizeof(T) == 8 ? g_opt.tail_m : g_opt.tail_m_f32;
+    const int tail_whole_T = sizeof(T) == 8 ? g_opt.tail_whole_m : g_opt.tail_whole_m_f32;
+    const bool tail_ok = tail_m_T > 0 && fused && g_opt.panel_impl == 1;
     auto use_tail = [&](int k0) {
-        return tail_ok && np_ - k0 <= ((k0 == 0 && g_opt.tail_whole_m > g_opt.tail_m) ? g_opt.tail_whole_m : g_opt.tail_m) &&
+        return tail_ok && np_ - k0 <= ((k0 == 0 && tail_whole_T > tail_m_T) ? tail_whole_T : tail_m_T) &&
                (np_ - k0) / NB_IN <= TAIL_MAXT &&
                tail_sync_words((np_ - k0) / NB_IN, (mp - k0) / NB_IN) * sizeof(unsigned) <= TAIL_SYNC_BYTES;
     };
@@ -655,17 +659,17 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         unsigned* sync = dag_sync + sync_next;
         if (!sync_zeroed) GPMC_HIP(hipMemsetAsync(sync, 0, words * sizeof(unsigned), st));
         sync_next += words;
-        static bool attr_done = false;
+        static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
-            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel),
+            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
             attr_done = true;
         }
         // grid = the Tt pairs + workers for the off-diagonal tiles: at most `workers` of them
         const int ntl = tail_tiles(Tt, Rt);
         const int grid = Tt + (ntl < workers ? ntl : workers);
-        hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), sizeof(TailShared), st,
-                           reinterpret_cast<double*>(W), ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
+        hipLaunchKernelGGL((tail_kernel<T>), dim3(grid), dim3(256), sizeof(TailShared), st,
+                           W, ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
                            g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt);
         GPMC_LAUNCH_CHECK();
         return 0;
@@ -708,7 +712,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (!sc) return fail(-1, "potrf: cannot create the look-ahead stream");
     }
     hipStream_t ps = sc->panel;
-    if (tail_ok && g_opt.la_dag) {
+    if (tail_ok && g_opt.la_dag && sizeof(T) == 8) {   // (float storage: the f32 GEMM outruns tile-DAG panels; 16384: 23.7 vs 20.3 ms)
         // ---- look-ahead with tile-DAG panels.  With c_k the panel starts:
         //   panel stream : D_0 | D_1 | D_2 | ...   D_{k+1} = ONE tile-DAG launch that factors panel k+1 after accumulating
         //                                          panel k's update of those columns as left-looking history (no separate
@@ -725,7 +729,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // back.  Words of G_k's flags: (tile columns of panel k+2) x (tile rows of its region), 0 when not used.
         auto next_nb = [&](int kk) { return (np_ - kk < la_nb(np_ - kk)) ? np_ - kk : la_nb(np_ - kk); };
         auto handover_words = [&](int k1, int k2) -> size_t {
-            if (!g_opt.dag_ahead || !g_opt.dag_hist || g_opt.gemm_impl != 1 || k2 >= np_ || hand_over(k2)) return 0;
+            if (sizeof(T) != 8 || !g_opt.dag_ahead || !g_opt.dag_hist || g_opt.gemm_impl != 1 || k2 >= np_ || hand_over(k2))
+                return 0;
             const int rows = mp_at(k1) - k2;
             if (rows <= g_opt.small_tile_m || rows % 128 || (np_ - k2) % 128) return 0;
             return (size_t)(next_nb(k2) / 128) * (size_t)(rows / 128);

@@ -65,15 +65,32 @@ __device__ inline unsigned tail_ld32(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one element of W with an sc1 (agent-scope relaxed atomic) load / store; storage type TS (double or float), the
+// arithmetic is f64 either way (as in the panel kernels: float storage, f64 panel arithmetic)
+__device__ inline double tail_ld_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const tail_u64*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline double tail_ld_sc1(const float* p) {
+    return (double)__uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline void tail_st_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<tail_u64*>(p), (tail_u64)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void tail_st_sc1(float* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint((float)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 64 x 64 tile W -> LDS [row][col] with sc1 loads (bytes another workgroup published in this launch)
-__device__ inline void tail_tile_in(double (*dst)[MP_LD], const double* __restrict__ src, int ld, int tid) {
+template <typename TS>
+__device__ inline void tail_tile_in(double (*dst)[MP_LD], const TS* __restrict__ src, int ld, int tid) {
     double v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int e = tid + 256 * t;
-        const tail_u64 u = __hip_atomic_load(reinterpret_cast<const tail_u64*>(src + (size_t)(e >> 6) * ld + (e & 63)),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[t] = __longlong_as_double((long long)u);
+        v[t] = tail_ld_sc1(src + (size_t)(e >> 6) * ld + (e & 63));
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -83,12 +100,12 @@ __device__ inline void tail_tile_in(double (*dst)[MP_LD], const double* __restri
 }
 
 // LDS [row][col] -> W with write-through stores; tail_drain() + barrier + the flag store follow
-__device__ inline void tail_tile_out(double* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
+template <typename TS>
+__device__ inline void tail_tile_out(TS* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int e = tid + 256 * t;
-        __hip_atomic_store(reinterpret_cast<tail_u64*>(dst + (size_t)(e >> 6) * ld + (e & 63)),
-                           (tail_u64)__double_as_longlong(src[e >> 6][e & 63]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tail_st_sc1(dst + (size_t)(e >> 6) * ld + (e & 63), src[e >> 6][e & 63]);
     }
 }
 __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -136,8 +153,9 @@ __host__ __device__ inline int tail_tiles(int T, int R) {
     return n;
 }
 
+template <typename TS>
 __global__ void __launch_bounds__(256, 2)
-tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
+tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
             const unsigned* __restrict__ gflag, int gmt) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
@@ -147,7 +165,7 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;
     unsigned* const abortw = sync;
     auto flag = [&](int col, int row) { return sync + 4 + col * R + row; };
-    double* const W0 = W + (size_t)k0 * ld + k0;                  // tile (0,0)
+    TS* const W0 = W + (size_t)k0 * ld + k0;                      // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
     // Block rows >= tri0 are riding rows that are upper-trapezoidal on entry (gpmc_potrf_tri: riding row r is zero left
@@ -206,13 +224,13 @@ tail_kernel(double* __restrict__ W, int ld, int k0, int T, int R, int H, int tri
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            D[m][h] = (pair && h <= m) ? tile(tl, tl)[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
+            D[m][h] = (pair && h <= m) ? (double)tile(tl, tl)[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
     const int xi = pair ? tl : ti, xl = pair ? tl - 1 : tl;       // the off-diagonal tile (xl < 0: none)
     if (xl >= 0) {
-        const double* src = tile(xi, xl);
+        const TS* src = tile(xi, xl);
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
-            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = *reinterpret_cast<const d2_t*>(&src[(size_t)row * ld + c2]);
+            *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = ld2<TS>(&src[(size_t)row * ld + c2]);
         }
     }
     __syncthreads();
