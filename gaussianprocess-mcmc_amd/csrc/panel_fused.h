@@ -250,10 +250,11 @@ panel_block_kernel(TS* __restrict__ W, int ld, int k0, int c0, int* __restrict__
         const double av = sh.Linv[p][ia][i];                       // A[i][k] = inv(L_pp)[i][k], lane (k, blk, i)
         const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T[p], 0.0, 0, 0, 0);
         T[p] = Y;
+        const double Yn = -Y;     // one sign flip per step instead of one per multiplier
 #pragma unroll
         for (int g = p + 1; g < 16; ++g) {
-            const double al = -Lout[4 * g + ia][4 * p + i];     // A[i][k] = -L[4g+i][4p+k]
-            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
+            const double al = Lout[4 * g + ia][4 * p + i];     // A[i][k] = -L[4g+i][4p+k]
+            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, T[g], 0, 0, 0);
         }
     }
 
@@ -320,10 +321,11 @@ trsm_block_kernel(const double* __restrict__ Ld, int ld, double* __restrict__ R,
         const double av = sh.Linv[p][ia][i];
         const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T[p], 0.0, 0, 0, 0);
         T[p] = Y;
+        const double Yn = -Y;     // one sign flip per step instead of one per multiplier
 #pragma unroll
         for (int g = p + 1; g < 16; ++g) {
-            const double al = -sh.Lout[4 * g + ia][4 * p + i];
-            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
+            const double al = sh.Lout[4 * g + ia][4 * p + i];
+            T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, T[g], 0, 0, 0);
         }
     }
 #pragma unroll

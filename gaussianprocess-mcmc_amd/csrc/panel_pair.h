@@ -112,10 +112,11 @@ panel_pair_kernel(TS* __restrict__ W, int ld, int c0, int* __restrict__ info, do
             const double av = sh.Linv[p][ia][i];
             const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T[p], 0.0, 0, 0, 0);
             T[p] = Y;
+            const double Yn = -Y;     // one sign flip per step instead of one per multiplier
 #pragma unroll
             for (int g = p + 1; g < 16; ++g) {
-                const double al = -Lout[4 * g + ia][4 * p + i];
-                T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T[g], 0, 0, 0);
+                const double al = Lout[4 * g + ia][4 * p + i];
+                T[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, T[g], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -177,7 +178,7 @@ panel_pair_kernel(TS* __restrict__ W, int ld, int c0, int* __restrict__ info, do
                     for (int h = 0; h <= m; ++h)
                         PD[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(aD[m][e2], bD[h][e2], PD[m][h], 0, 0, 0);
             if (b >= 2) {
-                const d2_t bT = *reinterpret_cast<const d2_t*>(&sh.B[16 * w + c][ko]);
+                const d2_t bT = -*reinterpret_cast<const d2_t*>(&sh.B[16 * w + c][ko]);   // the update's minus sign, once
 #pragma unroll
                 for (int gb = 0; gb < 16; gb += 8) {
                     d2_t aT[8];
@@ -187,7 +188,7 @@ panel_pair_kernel(TS* __restrict__ W, int ld, int c0, int* __restrict__ info, do
                     for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
                         for (int g = 0; g < 8; ++g)
-                            T2[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aT[g][e2], bT[e2], T2[gb + g], 0, 0, 0);
+                            T2[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[g][e2], bT[e2], T2[gb + g], 0, 0, 0);
                 }
             }
         }
@@ -216,10 +217,11 @@ panel_pair_kernel(TS* __restrict__ W, int ld, int c0, int* __restrict__ info, do
             const double av = sh.Linv[p][ia][i];
             const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, T2[p], 0.0, 0, 0, 0);
             T2[p] = Y;
+            const double Yn = -Y;
 #pragma unroll
             for (int g = p + 1; g < 16; ++g) {
-                const double al = -Lout[4 * g + ia][4 * p + i];
-                T2[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, T2[g], 0, 0, 0);
+                const double al = Lout[4 * g + ia][4 * p + i];
+                T2[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, T2[g], 0, 0, 0);
             }
         }
 #pragma unroll

@@ -246,7 +246,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 #pragma unroll 2
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;
-            const d2_t bT = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);
+            const d2_t bT = -*reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);   // the update's minus sign, once
 #pragma unroll
             for (int gb = 0; gb < 16; gb += 8) {
                 d2_t aT[8];
@@ -256,7 +256,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
                 for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
                     for (int g = 0; g < 8; ++g)
-                        X[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aT[g][e2], bT[e2], X[gb + g], 0, 0, 0);
+                        X[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[g][e2], bT[e2], X[gb + g], 0, 0, 0);
             }
             if (pair) {     // rows of L_{tl,col} are in Ls
                 d2_t bD[4], aD[4];
@@ -367,10 +367,11 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
                 const double av = sh.Linv[p][ia][i];
                 const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, X[p], 0.0, 0, 0, 0);
                 X[p] = Y;
+                const double Yn = -Y;          // one sign flip per step instead of one per multiplier
 #pragma unroll
                 for (int g = p + 1; g < 16; ++g) {
-                    const double al = -Lout[4 * g + ia][4 * p + i];
-                    X[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Y, X[g], 0, 0, 0);
+                    const double al = Lout[4 * g + ia][4 * p + i];
+                    X[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, X[g], 0, 0, 0);
                 }
             }
             TAIL_STAMP(4);
