@@ -238,9 +238,9 @@ int gpmc_debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info
    dbg_dev (>= 16 * 64 u64) until this is called again with NULL */
 int gpmc_debug_tail_stamps(unsigned long long* dbg_dev) { gpmc::g_tail_dbg = dbg_dev; return 0; }
 int gpmc_profile_begin(void) { return profile_begin(); }
-int gpmc_profile_read(double* out3) {
-    if (!out3) return fail(-1, "gpmc_profile_read: null out");
-    return profile_read(out3);
+int gpmc_profile_read(double* out6) {
+    if (!out6) return fail(-1, "gpmc_profile_read: null out");
+    return profile_read(out6);
 }
 
 #define S_(x) reinterpret_cast<hipStream_t>(x)

@@ -414,7 +414,17 @@ struct Prof {
     double flops = 0.0;
     long launches = 0;
 };
-static Prof g_prof;
+static Prof g_prof;       // trailing-update GEMM launches
+static Prof g_prof_dag;   // tile-DAG launches (panels and tail)
+static int prof_mark2(hipStream_t s) {
+    if (g_prof_dag.used == g_prof_dag.ev.size()) {
+        hipEvent_t e;
+        GPMC_HIP(hipEventCreate(&e));
+        g_prof_dag.ev.push_back(e);
+    }
+    GPMC_HIP(hipEventRecord(g_prof_dag.ev[g_prof_dag.used++], s));
+    return 0;
+}
 static int prof_mark(hipStream_t s) {
     if (g_prof.used == g_prof.ev.size()) {
         hipEvent_t e;
@@ -429,9 +439,13 @@ int profile_begin() {
     g_prof.used = 0;
     g_prof.flops = 0.0;
     g_prof.launches = 0;
+    g_prof_dag.used = 0;
+    g_prof_dag.flops = 0.0;
+    g_prof_dag.launches = 0;
     return 0;
 }
-int profile_read(double* out) {   // out: [0] total ms in the kernel, [1] launches, [2] algorithmic flops
+int profile_read(double* out) {   // out: [0] total ms in the trailing-update kernel, [1] launches, [2] algorithmic flops;
+                                  // [3..5] the same for the tile-DAG kernel (events on the stream each launch went to)
     g_prof.on = false;
     double ms = 0.0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
@@ -443,6 +457,16 @@ int profile_read(double* out) {   // out: [0] total ms in the kernel, [1] launch
     out[0] = ms;
     out[1] = (double)g_prof.launches;
     out[2] = g_prof.flops;
+    double ms2 = 0.0;
+    for (size_t i = 0; i + 1 < g_prof_dag.used; i += 2) {
+        GPMC_HIP(hipEventSynchronize(g_prof_dag.ev[i + 1]));
+        float t = 0.f;
+        GPMC_HIP(hipEventElapsedTime(&t, g_prof_dag.ev[i], g_prof_dag.ev[i + 1]));
+        ms2 += t;
+    }
+    out[3] = ms2;
+    out[4] = (double)g_prof_dag.launches;
+    out[5] = g_prof_dag.flops;
     return 0;
 }
 
@@ -668,10 +692,20 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // grid = the Tt pairs + workers for the off-diagonal tiles: at most `workers` of them
         const int ntl = tail_tiles(Tt, Rt);
         const int grid = Tt + (ntl < workers ? ntl : workers);
+        if (g_prof.on) {
+            int rcp = prof_mark2(st);
+            if (rcp) return rcp;
+            // algorithmic flops of the launch: the H history columns applied to the trapezoid, then the trapezoid's own
+            // factorisation -- m^3/3 for the m x m triangle + m^2 per row below it (riding rows not counted)
+            const double m = 64.0 * Tt, below = (double)(np_ - k0) - m, K = 64.0 * Hh;
+            g_prof_dag.flops += 2.0 * K * (0.5 * m * (m + 1.0) + below * m) + m * m * m / 3.0 + below * m * m;
+            g_prof_dag.launches++;
+        }
         hipLaunchKernelGGL((tail_kernel<T>), dim3(grid), dim3(256), sizeof(TailShared), st,
                            W, ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
                            g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt);
         GPMC_LAUNCH_CHECK();
+        if (g_prof.on) return prof_mark2(st);
         return 0;
     };
     auto tail_from = [&](int k0) -> int {

@@ -141,10 +141,11 @@ def profile_begin():
 
 
 def profile_read():
-    """(total_ms, launches, algorithmic_flops) of the trailing-update kernel since profile_begin()"""
-    out = (c_double * 3)()
+    """((total_ms, launches, algorithmic_flops) of the trailing-update kernel, the same of the tile-DAG kernel) since
+    profile_begin()"""
+    out = (c_double * 6)()
     check(lib().gpmc_profile_read(out), 'gpmc_profile_read')
-    return float(out[0]), int(out[1]), float(out[2])
+    return (float(out[0]), int(out[1]), float(out[2])), (float(out[3]), int(out[4]), float(out[5]))
 
 
 def pad(n):

@@ -206,11 +206,13 @@ int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
  * The stream passed to gpmc_plan_create must still be valid; the workspace is not touched. */
 int gpmc_plan_destroy(gpmc_plan* p);
 
-/* instrumentation of the dominant kernel (the trailing SYRK update of gpmc_potrf): between begin and read every
- * launch of it is bracketed by HIP events on its stream; read() returns out3 = {total ms inside the kernel,
- * number of launches, algorithmic flops (2 K x lower-triangle elements updated)}.  Not for graph capture. */
+/* instrumentation of the two kernels of the factorisation: between begin and read every launch of the trailing SYRK
+ * update and of the tile-DAG kernel (look-ahead panels, tail) is bracketed by HIP events on the stream it goes to;
+ * read() returns out6 = {total ms inside the update kernel, number of launches, algorithmic flops (2 K x
+ * lower-triangle elements updated); the same three for the tile-DAG kernel (history + m^3/3 + m^2 per row below)}.
+ * Not for graph capture. */
 int gpmc_profile_begin(void);
-int gpmc_profile_read(double* out3);
+int gpmc_profile_read(double* out6);
 
 /* tuning knobs (process-wide, not thread-safe; defaults are the measured auto rules -- csrc/gpmc_common.h `Options`
  * documents each): schedule "outer_nb" (0 = auto, else a multiple of 128), "lookahead" (-1 auto / 0 / 1), "la_min_np",
