@@ -754,14 +754,32 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         //   main stream  : G_0 | G_1 | G_2 | ...   G_k = columns [c_{k+2}, np_) -= panel k (big tiles), back to back
         // G_k waits for D_k; D_{k+1} waits for G_{k-1} (which brought its columns up to panel k-1).  The hand-over tail is
         // one more tile-DAG launch with panel k as history.
+        // Outer block and panel workers by remaining columns (swept with the in-launch hand-over in place, ms/eval,
+        // scripts/dag_sweep.sh): a panel launch no longer has to fit under ONE GEMM, so deeper panels (better GEMMs: 43 TF/s
+        // at K = 256, 53 at 512) pay from the start, and the fewer CU slots the panel holds the more the GEMM keeps -- as
+        // long as the panel chain still keeps up:  N = 8192: NB 256 4.77, 384 4.67, 512 4.70;  9216: 6.35 / 6.21 / 6.17;
+        // 10240 NB 512: 128 workers 8.63, 160 8.21, 224 8.01, 256 8.09 (NB 256: 8.56);  12288 NB 512: 96 workers 15.07,
+        // 128 13.69, 160 12.95, 192 13.44, 256 13.81 (NB 256: 13.95);  16384 NB 512: 96 31.5, 128 28.5, 160 29.1, 256 30.5
+        // (NB 256: 30.6; NB 1024 / 224 workers 28.3).
+        auto la_nb_dag = [&](int rem) {
+            if (g_opt.outer_nb > 0) return NB;
+            (void)rem;                       // by problem size: switching 512 -> 384 below 9216 remaining columns
+            return np_ >= 9216 ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
+        };
+        auto panel_workers = [&](int nb, int rem) {
+            if (g_opt.dag_workers > 0) return g_opt.dag_workers;
+            (void)rem;   // by problem size too: more workers as the remaining columns shrink loses (12288: 13.54 vs 12.95)
+            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : 224);
+            return nb / 2;
+        };
         hipEvent_t pe, ge = nullptr;
-        int nbk = la_nb(np_);
+        int nbk = la_nb_dag(np_);
         if (nbk > np_) nbk = np_;
         // In-launch hand-over (dag_ahead): G_k -- the update of the columns beyond panel k+1 by panel k -- processes the
         // tiles of panel k+2's columns first and flags each one (gemm4.h), and D_{k+2} gates its tiles on those flags
         // instead of on G_k's end: the panel chain runs up to a step ahead of the GEMM chain, which then runs back to
         // back.  Words of G_k's flags: (tile columns of panel k+2) x (tile rows of its region), 0 when not used.
-        auto next_nb = [&](int kk) { return (np_ - kk < la_nb(np_ - kk)) ? np_ - kk : la_nb(np_ - kk); };
+        auto next_nb = [&](int kk) { return (np_ - kk < la_nb_dag(np_ - kk)) ? np_ - kk : la_nb_dag(np_ - kk); };
         auto handover_words = [&](int k1, int k2) -> size_t {
             if (sizeof(T) != 8 || !g_opt.dag_ahead || !g_opt.dag_hist || g_opt.gemm_impl != 1 || k2 >= np_ || hand_over(k2))
                 return 0;
@@ -778,7 +796,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 const int k1 = k0 + nb;
                 if (k1 >= np_) break;
                 if (hand_over(k1)) { total += tail_sync_words((np_ - k1) / NB_IN, (mp - k1) / NB_IN); break; }
-                nb = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
+                nb = (np_ - k1 < la_nb_dag(np_ - k1)) ? np_ - k1 : la_nb_dag(np_ - k1);
                 total += handover_words(k1, k1 + nb);
                 k0 = k1;
             }
@@ -807,7 +825,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
                 return dag_launch(k1, (np_ - k1) / NB_IN, mp, nbk / NB_IN, s, g_opt.tail_workers);
             }
-            const int nbn = (np_ - k1 < la_nb(np_ - k1)) ? np_ - k1 : la_nb(np_ - k1);
+            const int nbn = (np_ - k1 < la_nb_dag(np_ - k1)) ? np_ - k1 : la_nb_dag(np_ - k1);
             const int k2 = k1 + nbn;
             if (ge && gf_prev == nullptr) rc = sc->edge_wait(ps, ge);
             if (rc) return rc;
@@ -817,8 +835,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 if (rc) return rc;
                 hist = 0;
             }
-            rc = dag_launch(k1, nbn / NB_IN, mp, hist, ps, g_opt.dag_workers > 0 ? g_opt.dag_workers : nbn / 2, gf_prev,
-                            gmt_prev);
+            rc = dag_launch(k1, nbn / NB_IN, mp, hist, ps, panel_workers(nbn, np_ - k1), gf_prev, gmt_prev);
             if (rc) return rc;
             hipEvent_t pe_next;
             rc = sc->edge_record(ps, &pe_next);
