@@ -40,7 +40,9 @@ namespace gpmc {
 
 constexpr int TAIL_MAXT = 128;                  // block columns of one launch
 // sync words of one launch: [0] abort word (16-byte slot), then flag[col][row], row stride R
-__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R; }
+// ... then busy[TAIL_CUS]: number of pairs inside their critical window on each CU (key = __smid()), see tail_kernel
+constexpr int TAIL_CUS = 1024;
+__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // default number of polls before giving up (~1 s)
 constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
@@ -56,6 +58,7 @@ struct TailShared {
     int fail;
     int ok;
     int tk;
+    int park;
 };
 static_assert(2 * sizeof(TailShared) <= 160 * 1024, "two tile workgroups per CU");
 
@@ -157,7 +160,7 @@ template <typename TS>
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
-            const unsigned* __restrict__ gflag, int gmt) {
+            const unsigned* __restrict__ gflag, int gmt, int park_on) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
@@ -165,6 +168,11 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;
     unsigned* const abortw = sync;
     auto flag = [&](int col, int row) { return sync + 4 + col * R + row; };
+    // A worker that shares its CU with a pair inside its critical window (from the wait for F(l-1) to the publication of
+    // F(l)) steps aside for that window: its MFMA stream slows the pair's factor wave (FP64 VALU, one wave) and the
+    // chain with it.  busy[cu] counts such pairs; a worker looks at its CU's word once per column (the load rides on
+    // the column's operand loads) and, if set, sleeps after that column until the word clears (bounded).
+    unsigned* const busy = (park_on ? sync + 4 + T * R + (__smid() & (TAIL_CUS - 1)) : nullptr);
     TS* const W0 = W + (size_t)k0 * ld + k0;                      // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
@@ -240,9 +248,13 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 
     // X -= L_{xi,col} L_{xl,col}^T (and, for the pair, (tl,tl) -= L_{tl,col} L_{tl,col}^T): both operands from W
     auto accumulate = [&](int col) {
+        unsigned bz = 0u;
+        if (!pair && busy != nullptr && tid == 0) bz = tail_ld32(busy);
         tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
         tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
+        if (!pair && tid == 0) sh.park = (int)bz;
         __syncthreads();
+        const bool park = !pair && busy != nullptr && sh.park != 0;
 #pragma unroll 2
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;
@@ -274,6 +286,12 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             }
         }
         __syncthreads();
+        if (park) {
+            if (tid == 0) {
+                for (int spins = 0; spins < 512 && tail_ld32(busy) != 0u; ++spins) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
     };
     // the pair of column 0 has no off-diagonal tile: its diagonal tile takes the history alone
     auto accumulate_D0 = [&](int col) {
@@ -335,6 +353,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 
     // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
     TAIL_STAMP(1);
+    if (pair && busy != nullptr && tid == 0) __hip_atomic_fetch_add(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (alive && xl >= 0) {
         alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid, spin_limit);
         TAIL_STAMP(2);
@@ -419,6 +438,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
         if (tid == 0) __hip_atomic_store(flag(tl, tl), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TAIL_STAMP(8);
     }
+    if (pair && busy != nullptr && tid == 0) __hip_atomic_fetch_add(busy, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pair || !alive) break;
     __syncthreads();      // LDS is reused by the next ticket
   }
