@@ -169,6 +169,31 @@ def test_log_marginal_options_agree(gp):
     assert vals[0][0] == vals[1][0] == vals[2][0]          # same blocking, different schedule: bitwise equal
 
 
+def test_tile_dag_schedule_knobs_do_not_change_the_bits(gp):
+    """worker parking beside a pair on the chain, worker counts and the look-ahead's outer block / hand-over are
+    schedules of the same arithmetic (every tile sums its updates in column order whoever does them): identical bits
+    at a one-launch size (4200) and a two-stream size (7300)."""
+    gpmc = gp['gpmc']
+    reset = {'tail_park': 1, 'tail_workers': 480, 'dag_workers': 0, 'outer_nb': 0, 'dag_ahead': 1, 'tail_m': 6144}
+    for n, variants in ((4200, [{}, {'tail_park': 0}, {'tail_workers': 96}]),
+                        (7300, [{}, {'tail_park': 0}, {'dag_workers': 64}, {'outer_nb': 256}, {'outer_nb': 512},
+                                {'dag_ahead': 0}, {'tail_m': 4096}])):
+        x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
+        vals = []
+        try:
+            for opts in variants:
+                for k, v in {**reset, **opts}.items():
+                    gpmc.set_option(k, v)
+                plan = gp['core'].LogMarginalPlan(x, g, 'rbf', settle=False)
+                vals.append((opts, plan([1.0, 10.0, 1.2]), plan([2.0, 7.0, 0.9])))
+                plan.close()
+        finally:
+            for k, v in reset.items():
+                gpmc.set_option(k, v)
+        for opts, a, b in vals[1:]:
+            assert (a, b) == vals[0][1:], (n, opts, a, b, vals[0])
+
+
 def test_log_marginal_reports_not_pd(gp):
     x = np.zeros((64, 1))                                  # all points coincide: K = sf2 * ones, S tiny
     plan = gp['core'].LogMarginalPlan(x, np.ones(64), 'rbf')

@@ -335,10 +335,11 @@ def _bench_like(n, d, seed=124):
     return rng.uniform(0., 10., (n, d)), rng.standard_normal(n) * 5.0
 
 
-@pytest.mark.parametrize('n', [4096, 8192])
+@pytest.mark.parametrize('n', [4096, 8192, 9300])
 def test_full_size_log_marginal(gp, n):
-    """configs 3 and 4 (N = 8192 / 4096, d = 2, fp64): against SciPy directly (a few seconds of CPU), plus
-    size-independent properties: bitwise repeatability and the residual (L L^T) v = (K + S) v."""
+    """configs 3 and 4 (N = 8192 / 4096, d = 2, fp64) and a size under the NB = 512 look-ahead rule (9300 -> 9344
+    columns): against SciPy directly (a few seconds of CPU), plus size-independent properties: bitwise repeatability and
+    the residual (L L^T) v = (K + S) v."""
     X, g = _bench_like(n, 2)
     hyp = [1.0, 10.0, 1.2]
     plan = gp['core'].LogMarginalPlan(X, g, 'rbf')
