@@ -172,7 +172,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // F(l)) steps aside for that window: its MFMA stream slows the pair's factor wave (FP64 VALU, one wave) and the
     // chain with it.  busy[cu] counts such pairs; a worker looks at its CU's word once per column (the load rides on
     // the column's operand loads) and, if set, sleeps after that column until the word clears (bounded).
-    unsigned* const busy = (park_on ? sync + 4 + T * R + (__smid() & (TAIL_CUS - 1)) : nullptr);
+    unsigned* const busy = ((park_on & 1) ? sync + 4 + T * R + (__smid() & (TAIL_CUS - 1)) : nullptr);
     TS* const W0 = W + (size_t)k0 * ld + k0;                      // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
@@ -189,7 +189,11 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     const int ntiles = tail_tiles(T, R);
     unsigned* const ticketw = sync + 1;
     bool alive = true;
-  for (;;) {     // a pair runs the body once; a worker once per ticket
+    // A pair executes the 64 x 64 factor exactly once, inside its critical window, and on most CUs nobody has run that
+    // code before (19 KB of the kernel): it would be fetched cold.  Pairs from column 2 on therefore run the body twice:
+    // a first pass that only factors an identity tile (same instructions, LDS only) while they have nothing to do yet.
+    bool warm = ((park_on & 4) != 0) && (int)blockIdx.x < T && (int)blockIdx.x >= 2;
+  for (;;) {     // a pair runs the body once (after its warm-up pass); a worker once per ticket
     int tl = 0, ti;
     if (pair) {
         tl = ti = (int)blockIdx.x;
@@ -210,14 +214,14 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // diagnostic (dbg != nullptr only from gpmc_debug_tail_stamps): s_memtime stamps of the pair workgroups
 #define TAIL_STAMP(k)                                                                  \
     do {                                                                               \
-        if (dbg != nullptr && pair && tid == 0) dbg[16 * tl + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (dbg != nullptr && pair && !warm && tid == 0) dbg[16 * tl + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
     TAIL_STAMP(0);
 
     // ---------------- the tile's start values may still be under way: with gflag the trailing update that brings these
     // columns up to date is RUNNING beside this launch and publishes the 128 x 128 tiles of these columns first
     // (gemm4.h, prio_cols): wait for the one (pair: the one or two) covering this workgroup's tiles
-    if (gflag != nullptr) {
+    if (gflag != nullptr && !warm) {
         const int ci = pair ? tl : ti, cl0 = pair ? (tl >= 1 ? tl - 1 : tl) : tl;
         if ((ci >> 1) < gmt) {      // (rows beyond the update's range are untouched by it)
             alive = tail_wait2(gflag + (cl0 >> 1) * gmt + (ci >> 1), gflag + (tl >> 1) * gmt + (ci >> 1), abortw, sh, tid,
@@ -232,9 +236,10 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            D[m][h] = (pair && h <= m) ? (double)tile(tl, tl)[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0;
+            D[m][h] = warm ? ((4 * (w + 4 * m) + i == 16 * h + c) ? 1.0 : 0.0)
+                           : ((pair && h <= m) ? (double)tile(tl, tl)[(size_t)(4 * (w + 4 * m) + i) * ld + 16 * h + c] : 0.0);
     const int xi = pair ? tl : ti, xl = pair ? tl - 1 : tl;       // the off-diagonal tile (xl < 0: none)
-    if (xl >= 0) {
+    if (xl >= 0 && !warm) {
         const TS* src = tile(xi, xl);
         for (int e = tid; e < 64 * 32; e += 256) {
             const int row = e >> 5, c2 = (e & 31) * 2;
@@ -318,7 +323,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 
     // ---------------- left-looking accumulation: first the H history columns to the left of this launch's columns
     // (final since an earlier launch: nothing to wait for), then this launch's columns as they are published
-    for (int col = -H; col < 0; ++col) {
+    for (int col = warm ? 0 : -H; col < 0; ++col) {
         if (zero_tile(xi, col)) continue;
         if (xl >= 0) accumulate(col);
         else accumulate_D0(col);
@@ -328,7 +333,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // wave 0 look at the next 64 columns of both operand rows at once and the loop runs through everything that is
     // ready without polling again; it blocks on a single column only when it has caught up with the producers.
     int ready_upto = 0;
-    for (int col = 0; col < xl && alive; ++col) {
+    for (int col = 0; col < xl && alive && !warm; ++col) {
         if (zero_tile(xi, col)) continue;
         if (col >= ready_upto) {
             if (tid < 64) {
@@ -353,8 +358,8 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 
     // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
     TAIL_STAMP(1);
-    if (pair && busy != nullptr && tid == 0) __hip_atomic_fetch_add(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (alive && xl >= 0) {
+    if (pair && !warm && busy != nullptr && tid == 0) __hip_atomic_fetch_add(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (alive && xl >= 0 && !warm) {
         alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid, spin_limit);
         TAIL_STAMP(2);
         if (alive) {
@@ -430,6 +435,10 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // ---------------- the diagonal tile: factor, publish
     if (alive && pair) {
         mp_factor64(D, Lout, sh.Praw, &sh.fail, sh.rsd, tid, k0 + 64 * tl);    // opens and closes with a barrier
+        if (warm) {
+            warm = false;
+            continue;
+        }
         TAIL_STAMP(7);
         if (tid == 0 && sh.fail != 0) atomicCAS(info, 0, sh.fail);
         tail_tile_out(tile(tl, tl), ld, Lout, tid);
