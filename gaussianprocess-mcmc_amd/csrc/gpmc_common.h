@@ -59,6 +59,7 @@ struct Options {
                               // look-ahead phase in front; 8192: 5.57 vs 5.0)
     int tail_m_f32 = 4096, tail_whole_m_f32 = 4096;   // the same two extents for float storage
     int tail_warm = 1;        // tile-DAG pairs run the factor once on an identity tile before their real pass (instruction cache, tail.h)
+    int tail_roles_by_index = 0;   // measurements only: pairs = blocks 0 .. T-1 (can deadlock into the spin limit when processes share a card)
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 480;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width

@@ -170,6 +170,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "tail_roles_by_index")) g_opt.tail_roles_by_index = value ? 1 : 0;
     else if (!strcmp(name, "tail_warm")) g_opt.tail_warm = value ? 1 : 0;
     else if (!strcmp(name, "dag_workers")) g_opt.dag_workers = value < 0 ? 0 : value;
     else if (!strcmp(name, "tail_m")) { if (value < 0 || value > 8192 || value % 64) return fail(-2, "tail_m must be a multiple of 64 in [0, 8192]"); g_opt.tail_m = value; }
@@ -216,6 +217,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "tail_roles_by_index")) return g_opt.tail_roles_by_index;
     if (!strcmp(name, "tail_warm")) return g_opt.tail_warm;
     if (!strcmp(name, "dag_workers")) return g_opt.dag_workers;
     if (!strcmp(name, "tail_m")) return g_opt.tail_m;

@@ -703,7 +703,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         }
         hipLaunchKernelGGL((tail_kernel<T>), dim3(grid), dim3(256), sizeof(TailShared), st,
                            W, ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
-                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt, (g_opt.tail_park ? 1 : 0) | (g_opt.tail_warm ? 4 : 0));
+                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt, (g_opt.tail_park ? 1 : 0) | (g_opt.tail_warm ? 4 : 0) | (g_opt.tail_roles_by_index ? 8 : 0));
         GPMC_LAUNCH_CHECK();
         if (g_prof.on) return prof_mark2(st);
         return 0;

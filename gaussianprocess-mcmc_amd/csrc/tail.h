@@ -13,18 +13,21 @@
 // The tile lives in registers for the workgroup's whole life (16 doubles per thread; diagonal tiles in the slab
 // layout of diag_mp.h, off-diagonal ones transposed as the TRSM wants them -- both are MFMA accumulator layouts, so a
 // tile is never converted) and its FINAL value is written once.
-// * Workgroups 0 .. T-1 are the pairs, one each, resident from the start: the critical chain never waits for a free
-//   worker.  Workgroups T .. grid-1 are WORKERS: each draws tickets (one agent-scope atomic add) and processes the
-//   off-diagonal tiles in column-major ticket order, so the number of CU slots the launch holds is the grid size the
-//   host picks, not the number of tiles -- beside the trailing GEMM of the look-ahead a launch with one workgroup
-//   per tile parks hundreds of waiting workgroups on slots the GEMM needs.
-// * Deadlock freedom without co-residency of the whole grid: a tile only waits for pairs (workgroups 0 .. T-1) and
-//   for tiles with LOWER tickets (earlier columns), which are held by resident workers or finished; a pair waits for
-//   tiles of earlier columns.  Blocks are dispatched in index order, so as soon as T + 1 workgroups are resident the
-//   lowest unfinished ticket always has everything it needs or is itself being worked on.  Other kernels (or another
-//   instance of this one) may share the chip.  Every spin is bounded all the same: a workgroup that gives up raises
-//   the abort word, every other spin sees it within 256 polls, all leave and *info becomes GPMC_TAIL_TIMEOUT -- the
-//   grid always drains.
+// * The first T workgroups of the launch that start running are the pairs, one per column (an arrival counter hands
+//   out the roles): the critical chain never waits for a free worker.  The others are WORKERS: each draws tickets (one
+//   agent-scope atomic add) and processes the off-diagonal tiles in column-major ticket order, so the number of CU
+//   slots the launch holds is the grid size the host picks, not the number of tiles -- beside the trailing GEMM of the
+//   look-ahead a launch with one workgroup per tile parks hundreds of waiting workgroups on slots the GEMM needs.
+// * Deadlock freedom without co-residency of the whole grid: a tile only waits for pairs and for tiles with LOWER
+//   tickets (earlier columns), which are held by running workers or finished; a pair waits for tiles of earlier
+//   columns.  Roles and tickets go to workgroups that are RUNNING, so as soon as T + 1 workgroups of the launch run
+//   -- anywhere on the chip -- the lowest unfinished ticket always has everything it needs or is itself being worked
+//   on.  Other kernels, or another process's instance of this one, may share the chip: as long as some launch can get
+//   its T + 1 workgroups in (512 slots; T <= 112), that one finishes and frees its slots.  (Roles by block index, the
+//   first version, tied each pair to the XCD its index is dealt to; two processes on one card then deadlocked now and
+//   then, each holding the XCDs the other's pairs were queued for.)  Every spin is bounded all the same: a workgroup
+//   that gives up raises the abort word, every other spin sees it within 256 polls, all leave and *info becomes
+//   GPMC_TAIL_TIMEOUT -- the grid always drains.
 // * Publishing = writing the tile to its place in W with write-through (sc1) stores, every storing wave draining its
 //   stores, a workgroup barrier, then ONE lane's agent-scope flag store; consumers poll the flag (one lane, relaxed
 //   sc1 loads, s_sleep between polls), pass a workgroup barrier and read the tile with sc1 loads -- the "8-byte agent
@@ -39,7 +42,7 @@
 namespace gpmc {
 
 constexpr int TAIL_MAXT = 128;                  // block columns of one launch
-// sync words of one launch: [0] abort word (16-byte slot), then flag[col][row], row stride R
+// sync words of one launch: [0] abort word, [1] ticket counter, [2] pair-role counter, then flag[col][row], row stride R
 // ... then busy[TAIL_CUS]: number of pairs inside their critical window on each CU (key = __smid()), see tail_kernel
 constexpr int TAIL_CUS = 1024;
 __host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS; }
@@ -182,21 +185,42 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // its updates of other tiles are skipped.  tri0 = R: no such rows.
     const int gb = k0 / 64;
     auto zero_tile = [&](int ti_, int col) { return ti_ >= tri0 && col + gb < ti_ - tri0; };
-    const bool pair = (int)blockIdx.x < T;        // pair of column blockIdx.x: owns (tl,tl) and, for tl >= 1, (tl,tl-1)
+    // Roles by ARRIVAL, not by block index: the first T workgroups of the launch that start running are the pairs of
+    // columns 0 .. T-1 (pair l owns (tl,tl) and, for tl >= 1, (tl,tl-1)), the others are workers.  Block indices are
+    // dealt to the 8 XCDs statically (b mod 8), so "pairs = blocks 0 .. T-1" ties each pair to one XCD: with a second
+    // process on the same card two launches could each fill some XCDs with waiting workers while their own pairs
+    // queue for the XCDs the other one holds -- a cycle that only the spin limit ended (seen once in five runs of two
+    // ranks on one card).  By arrival, a launch has all its pairs as soon as T of its workgroups run ANYWHERE.
+    // Only the first 2T + 16 blocks of the grid are candidates (the blocks the dispatcher places first: one per CU,
+    // spread over the XCDs like the by-index pairs were -- with all blocks as candidates the pairs land wherever the
+    // launch's first microsecond puts them, and the tail launch of N = 8192 took 2.49 instead of 2.36 ms); a candidate
+    // that finds the T roles taken is a worker like the rest.
+    unsigned* const ticketw = sync + 1;
+    int role = (int)blockIdx.x;
+    const bool by_index = (park_on & 8) != 0;     // (bit 3: measurements only -- option tail_roles_by_index)
+    if (!by_index) {
+        role = T;
+        if ((int)blockIdx.x < 2 * T + 16) {
+            if (tid == 0) sh.tk = (int)__hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            role = sh.tk;
+            __syncthreads();
+        }
+    }
+    const bool pair = role < T;
     if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
     else if (wprio == 1) __builtin_amdgcn_s_setprio(1);
     else if (wprio == 2) __builtin_amdgcn_s_setprio(2);
     const int ntiles = tail_tiles(T, R);
-    unsigned* const ticketw = sync + 1;
     bool alive = true;
     // A pair executes the 64 x 64 factor exactly once, inside its critical window, and on most CUs nobody has run that
     // code before (19 KB of the kernel): it would be fetched cold.  Pairs from column 2 on therefore run the body twice:
     // a first pass that only factors an identity tile (same instructions, LDS only) while they have nothing to do yet.
-    bool warm = ((park_on & 4) != 0) && (int)blockIdx.x < T && (int)blockIdx.x >= 2;
+    bool warm = ((park_on & 4) != 0) && pair && role >= 2;
   for (;;) {     // a pair runs the body once (after its warm-up pass); a worker once per ticket
     int tl = 0, ti;
     if (pair) {
-        tl = ti = (int)blockIdx.x;
+        tl = ti = role;
     } else {
         if (tid == 0) sh.tk = (int)__hip_atomic_fetch_add(ticketw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -253,13 +277,15 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 
     // X -= L_{xi,col} L_{xl,col}^T (and, for the pair, (tl,tl) -= L_{tl,col} L_{tl,col}^T): both operands from W
     auto accumulate = [&](int col) {
+        // (pairs step aside too: with roles by arrival two pairs can share a CU; a pair only accumulates OUTSIDE its own
+        // window, so the word it reads never counts itself)
         unsigned bz = 0u;
-        if (!pair && busy != nullptr && tid == 0) bz = tail_ld32(busy);
+        if (busy != nullptr && tid == 0) bz = tail_ld32(busy);
         tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
         tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
-        if (!pair && tid == 0) sh.park = (int)bz;
+        if (tid == 0) sh.park = (int)bz;
         __syncthreads();
-        const bool park = !pair && busy != nullptr && sh.park != 0;
+        const bool park = busy != nullptr && sh.park != 0;
 #pragma unroll 2
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;

@@ -174,9 +174,10 @@ def test_tile_dag_schedule_knobs_do_not_change_the_bits(gp):
     schedules of the same arithmetic (every tile sums its updates in column order whoever does them): identical bits
     at a one-launch size (4200) and a two-stream size (7300)."""
     gpmc = gp['gpmc']
-    reset = {'tail_park': 1, 'tail_workers': 480, 'dag_workers': 0, 'outer_nb': 0, 'dag_ahead': 1, 'tail_m': 6144}
-    for n, variants in ((4200, [{}, {'tail_park': 0}, {'tail_workers': 96}]),
-                        (7300, [{}, {'tail_park': 0}, {'dag_workers': 64}, {'outer_nb': 256}, {'outer_nb': 512},
+    reset = {'tail_park': 1, 'tail_warm': 1, 'tail_workers': 480, 'dag_workers': 0, 'outer_nb': 0, 'dag_ahead': 1,
+             'tail_m': 6144}
+    for n, variants in ((4200, [{}, {'tail_park': 0}, {'tail_warm': 0}, {'tail_workers': 96}]),
+                        (7300, [{}, {'tail_park': 0}, {'tail_warm': 0}, {'dag_workers': 64}, {'outer_nb': 256}, {'outer_nb': 512},
                                 {'dag_ahead': 0}, {'tail_m': 4096}])):
         x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
         vals = []

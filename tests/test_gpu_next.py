@@ -219,3 +219,23 @@ def test_two_ranks_run_independent_device_chains(tmp_path):
                        env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count('ok') == 2
+
+
+def test_two_processes_share_one_card_at_full_size():
+    """Two ranks of the bench at N = 8192 on ONE card (gloo; the driver's real launches have a card per rank): each rank's
+    tile-DAG launches compete with the other's for CU slots.  With pair roles tied to block indices (and so to XCDs)
+    this ended in the kernel's spin limit (info = -1001) about once in seven runs; with roles by arrival among the first
+    blocks of the grid (csrc/tail.h) both ranks finish and the line is whole-job throughput of two ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPMC_DIST_BACKEND='gloo')
+    env.pop('RANK', None), env.pop('WORLD_SIZE', None), env.pop('LOCAL_RANK', None)
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '2',
+                            '--metric-only'], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+        d = json.loads(line)
+        assert d['n_gpus'] == 2 and d['value'] > 0, d
