@@ -42,10 +42,11 @@
 namespace gpmc {
 
 constexpr int TAIL_MAXT = 128;                  // block columns of one launch
-// sync words of one launch: [0] abort word, [1] ticket counter, [2] pair-role counter, then flag[col][row], row stride R
+// sync words of one launch: [0] abort word, [1] ticket counter, then flag[col][row], row stride R
 // ... then busy[TAIL_CUS]: number of pairs inside their critical window on each CU (key = __smid()), see tail_kernel
 constexpr int TAIL_CUS = 1024;
-__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS; }
+// ... then claim[TAIL_MAXT]: pair role l has been taken
+__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS + TAIL_MAXT; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // default number of polls before giving up (~1 s)
 constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
@@ -185,27 +186,46 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // its updates of other tiles are skipped.  tri0 = R: no such rows.
     const int gb = k0 / 64;
     auto zero_tile = [&](int ti_, int col) { return ti_ >= tri0 && col + gb < ti_ - tri0; };
-    // Roles by ARRIVAL, not by block index: the first T workgroups of the launch that start running are the pairs of
-    // columns 0 .. T-1 (pair l owns (tl,tl) and, for tl >= 1, (tl,tl-1)), the others are workers.  Block indices are
-    // dealt to the 8 XCDs statically (b mod 8), so "pairs = blocks 0 .. T-1" ties each pair to one XCD: with a second
-    // process on the same card two launches could each fill some XCDs with waiting workers while their own pairs
-    // queue for the XCDs the other one holds -- a cycle that only the spin limit ended (seen once in five runs of two
-    // ranks on one card).  By arrival, a launch has all its pairs as soon as T of its workgroups run ANYWHERE.
-    // Only the first 2T + 16 blocks of the grid are candidates (the blocks the dispatcher places first: one per CU,
-    // spread over the XCDs like the by-index pairs were -- with all blocks as candidates the pairs land wherever the
-    // launch's first microsecond puts them, and the tail launch of N = 8192 took 2.49 instead of 2.36 ms); a candidate
-    // that finds the T roles taken is a worker like the rest.
+    // Roles.  Block l < T is the pair of column l (owns (l,l) and, for l >= 1, (l,l-1)), the others are workers -- but a
+    // pair role belongs to whoever CLAIMS it first (claim[l], one word per column), and blocks T .. 2T+15 look, ~8 us
+    // after they start, for roles nobody has claimed and take one over; the late owner then finds its role gone and is
+    // a worker.  Why: block indices are dealt to the 8 XCDs statically (b mod 8), so "pairs = blocks 0 .. T-1" alone
+    // ties every pair to one XCD, and with a second process on the same card two launches could each fill some XCDs
+    // with waiting workers while their own pairs queued for the XCDs the other one held -- a cycle only the spin limit
+    // ended (info = -1001 in 2 of 15 runs of two ranks on one card).  With take-over a launch has all its pairs as soon
+    // as enough of its first blocks run ANYWHERE; with the chip to itself every block claims its own role within the
+    // launch's first microsecond and nothing changes (handing the roles out purely by arrival put the pairs on
+    // arbitrary CUs and cost 1-4 % at N = 8192).
     unsigned* const ticketw = sync + 1;
+    unsigned* const claim = sync + 4 + T * R + TAIL_CUS;
     int role = (int)blockIdx.x;
-    const bool by_index = (park_on & 8) != 0;     // (bit 3: measurements only -- option tail_roles_by_index)
-    if (!by_index) {
-        role = T;
-        if ((int)blockIdx.x < 2 * T + 16) {
-            if (tid == 0) sh.tk = (int)__hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            role = sh.tk;
-            __syncthreads();
+    const bool by_index = (park_on & 8) != 0;     // (bit 3: no claims, measurements only -- option tail_roles_by_index)
+    if (!by_index && role < 2 * T + 16) {
+        if (tid < 64) {       // wave 0
+            int got = T;      // worker
+            if (role < T) {
+                unsigned old = 1u;
+                if (tid == 0) old = atomicCAS(claim + role, 0u, 1u);
+                if (__shfl(old, 0) == 0u) got = role;
+            } else {
+                for (int spins = 0; spins < 32; ++spins) __builtin_amdgcn_s_sleep(16);      // ~8 us
+                for (int base = 0; base < T && got == T; base += 64) {
+                    const int l = base + tid;
+                    unsigned long long m = __ballot(l < T && tail_ld32(claim + l) == 0u);
+                    while (m != 0ull && got == T) {           // (wave-uniform)
+                        const int j = (int)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        unsigned old = 1u;
+                        if (tid == 0) old = atomicCAS(claim + base + j, 0u, 1u);
+                        if (__shfl(old, 0) == 0u) got = base + j;
+                    }
+                }
+            }
+            if (tid == 0) sh.tk = got;
         }
+        __syncthreads();
+        role = sh.tk;
+        __syncthreads();
     }
     const bool pair = role < T;
     if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups

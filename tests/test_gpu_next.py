@@ -224,8 +224,8 @@ def test_two_ranks_run_independent_device_chains(tmp_path):
 def test_two_processes_share_one_card_at_full_size():
     """Two ranks of the bench at N = 8192 on ONE card (gloo; the driver's real launches have a card per rank): each rank's
     tile-DAG launches compete with the other's for CU slots.  With pair roles tied to block indices (and so to XCDs)
-    this ended in the kernel's spin limit (info = -1001) about once in seven runs; with roles by arrival among the first
-    blocks of the grid (csrc/tail.h) both ranks finish and the line is whole-job throughput of two ranks."""
+    this ended in the kernel's spin limit (info = -1001) about once in seven runs; with unclaimed pair roles taken over by
+    the grid's next blocks (csrc/tail.h) both ranks finish and the line is whole-job throughput of two ranks."""
     import json
     import subprocess
     import sys
