@@ -13,8 +13,8 @@ echo "== full bench extras"
 timeout -k 10 300 python bench.py --metric-only --full > gpurun_out/bench_full.json 2>/dev/null; python3 -c "
 import json; d=json.load(open('gpurun_out/bench_full.json')); print(d['value'], d['extra'])"
 echo "== 2 ranks on one card (gloo rehearsal of the self-spawned launch)"
-GPMC_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --no-cpu 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['n_gpus'], d['value'], d['ms_per_step'])"
+GPMC_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --no-cpu 2>gpurun_out/two_ranks.err | python3 -c "
+import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['n_gpus'], d['value'], d['ms_per_step'])"
 echo "== N=4096 bench line (config 4's per-GPU workload)"
 timeout -k 10 300 python bench.py --n 4096 --metric-only 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"
