@@ -60,6 +60,10 @@ struct Options {
     int tail_m_f32 = 4096, tail_whole_m_f32 = 4096;   // the same two extents for float storage
     int tail_warm = 1;        // tile-DAG pairs run the factor once on an identity tile before their real pass (instruction cache, tail.h)
     int tail_roles_by_index = 0;   // measurements only: pairs = blocks 0 .. T-1 (can deadlock into the spin limit when processes share a card)
+    int tail_acc16 = 1;       // tile-DAG off-diagonal accumulation on v_mfma_f64_16x16x4 (0: the 4x4x4 form, same bits; tail.h)
+    int tail_prefetch_t = 72; // whole / tail tile-DAG launches of at least this many tile columns prefetch the next column's
+                              // operands under the MFMA phase (0 = never; needs tail_acc16)
+    int dag_prefetch = 0;     // ... look-ahead panel launches too (8192: +-0, 9216: -0.9 %, 12288: +2 %)
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 480;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width

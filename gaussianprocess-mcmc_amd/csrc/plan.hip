@@ -170,6 +170,9 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
+    else if (!strcmp(name, "tail_prefetch_t")) g_opt.tail_prefetch_t = value;
+    else if (!strcmp(name, "dag_prefetch")) g_opt.dag_prefetch = value ? 1 : 0;
     else if (!strcmp(name, "tail_roles_by_index")) g_opt.tail_roles_by_index = value ? 1 : 0;
     else if (!strcmp(name, "tail_warm")) g_opt.tail_warm = value ? 1 : 0;
     else if (!strcmp(name, "dag_workers")) g_opt.dag_workers = value < 0 ? 0 : value;
@@ -217,6 +220,9 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
+    if (!strcmp(name, "tail_prefetch_t")) return g_opt.tail_prefetch_t;
+    if (!strcmp(name, "dag_prefetch")) return g_opt.dag_prefetch;
     if (!strcmp(name, "tail_roles_by_index")) return g_opt.tail_roles_by_index;
     if (!strcmp(name, "tail_warm")) return g_opt.tail_warm;
     if (!strcmp(name, "dag_workers")) return g_opt.dag_workers;

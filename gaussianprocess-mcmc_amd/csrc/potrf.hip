@@ -685,8 +685,11 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         sync_next += words;
         static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
-            GPMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
+            const void* fns[] = {reinterpret_cast<const void*>(tail_kernel<T, 0, false>),
+                                 reinterpret_cast<const void*>(tail_kernel<T, 4, false>),
+                                 reinterpret_cast<const void*>(tail_kernel<T, 4, true>)};
+            for (const void* fn : fns)
+                GPMC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
             attr_done = true;
         }
         // grid = the Tt pairs + workers for the off-diagonal tiles: at most `workers` of them
@@ -701,9 +704,19 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             g_prof_dag.flops += 2.0 * K * (0.5 * m * (m + 1.0) + below * m) + m * m * m / 3.0 + below * m * m;
             g_prof_dag.launches++;
         }
-        hipLaunchKernelGGL((tail_kernel<T>), dim3(grid), dim3(256), sizeof(TailShared), st,
-                           W, ldw, k0, Tt, Rt, Hh, (mp_rows - ntri - k0) / NB_IN, sync, info_dev,
-                           g_tail_dbg, st == s ? 0 : g_opt.dag_wprio, (unsigned)g_opt.tail_spin_limit, gflag, gmt, (g_opt.tail_park ? 1 : 0) | (g_opt.tail_warm ? 4 : 0) | (g_opt.tail_roles_by_index ? 8 : 0));
+        const int tflags = (g_opt.tail_park ? 1 : 0) | (g_opt.tail_warm ? 4 : 0) | (g_opt.tail_roles_by_index ? 8 : 0);
+#define GPMC_TAIL_LAUNCH(A16, PRE)                                                                                       \
+        hipLaunchKernelGGL((tail_kernel<T, A16, PRE>), dim3(grid), dim3(256), sizeof(TailShared), st, W, ldw, k0, Tt, Rt, Hh, \
+                           (mp_rows - ntri - k0) / NB_IN, sync, info_dev, g_tail_dbg, st == s ? 0 : g_opt.dag_wprio,          \
+                           (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags)
+        // variants (tail.h): the 4x4x4 accumulation (cross-checks only); the 16x16x4 accumulation; the same with the next
+        // column's operands prefetched -- for launches whose time is their bulk, not their pivot chain
+        const bool pre = g_opt.tail_acc16 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)
+                                                      : g_opt.dag_prefetch != 0);
+        if (!g_opt.tail_acc16) GPMC_TAIL_LAUNCH(0, false);
+        else if (pre) GPMC_TAIL_LAUNCH(4, true);
+        else GPMC_TAIL_LAUNCH(4, false);
+#undef GPMC_TAIL_LAUNCH
         GPMC_LAUNCH_CHECK();
         if (g_prof.on) return prof_mark2(st);
         return 0;

@@ -117,6 +117,37 @@ __device__ inline void tail_tile_out(TS* __restrict__ dst, int ld, const double 
 }
 __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Operand tiles for the accumulation: two adjacent elements per lane and load (16 bytes of f64, 8 of f32) through a raw
+// buffer descriptor with the sc1 (agent scope) cache policy -- the same visibility as the sc1 global loads above, but
+// the 8 loads of a tile share ONE per-lane offset register and take their row step from an SGPR, and the loaded bits
+// stay untouched in registers until they are staged (a conversion at load time would wait for the load).
+typedef unsigned int tail_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tail_u2 __attribute__((ext_vector_type(2)));
+template <typename TS> struct TailRaw;
+template <> struct TailRaw<double> {
+    typedef tail_u4 type;
+    __device__ static inline type load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);      // aux bit 4 = sc1 on gfx94x / gfx950
+    }
+    __device__ static inline d2_t value(type v) { return __builtin_bit_cast(d2_t, v); }
+};
+template <> struct TailRaw<float> {
+    typedef tail_u2 type;
+    __device__ static inline type load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16);
+    }
+    __device__ static inline d2_t value(type v) {
+        d2_t o;
+        o[0] = (double)__uint_as_float(v[0]);
+        o[1] = (double)__uint_as_float(v[1]);
+        return o;
+    }
+};
+template <typename TS>
+__device__ inline __amdgpu_buffer_rsrc_t tail_rsrc(const TS* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
 // all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
 // acquire = true: the bytes behind the flags were written with PLAIN stores and released (the GEMM's hand-over tiles):
 // the polling lane follows its poll with an agent-scope acquire (drops this CU's stale L1 lines) before the barrier
@@ -160,7 +191,7 @@ __host__ __device__ inline int tail_tiles(int T, int R) {
     return n;
 }
 
-template <typename TS>
+template <typename TS, int ACC16, bool PRE>
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
@@ -275,7 +306,11 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     }
     // ---------------- tiles into registers
     double D[4][4];     // (tl,tl), slab layout: lane (i, c) of D[m][h] = element [4 (w + 4 m) + i][16 h + c]
-    double X[16];       // off-diagonal tile, transposed: lane (i, c) of X[g] = element [16 w + c][4 g + i]
+    // off-diagonal tile, transposed: lane (i, c) of XG(g) = element [16 w + c][4 g + i]; the four slabs g = 4b .. 4b+3 are
+    // the four registers of ONE v_mfma_f64_16x16x4 accumulator (D row = (l>>4) + 4 reg, gpmc_common.h), so the same
+    // registers serve both MFMA shapes
+    d4_t X4[4];
+#define XG(g) X4[(g) >> 2][(g) & 3]
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -292,34 +327,79 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) X[g] = (xl >= 0) ? sh.Ls[16 * w + c][4 * g + i] : 0.0;
+    for (int g = 0; g < 16; ++g) XG(g) = (xl >= 0) ? sh.Ls[16 * w + c][4 * g + i] : 0.0;
     __syncthreads();
 
     // X -= L_{xi,col} L_{xl,col}^T (and, for the pair, (tl,tl) -= L_{tl,col} L_{tl,col}^T): both operands from W
-    auto accumulate = [&](int col) {
+    // The operand tiles of a column travel W -> registers (fetch) -> LDS (stage).  When the NEXT column is already known
+    // to be published (history columns; columns inside the ready prefix), its loads are issued before this column's
+    // MFMA phase and land under it (a workgroup barrier does not wait for vector loads at workgroup scope): the load
+    // round trip, otherwise exposed once per column and hidden only by the other workgroup of the CU, disappears.
+    typename TailRaw<TS>::type va[8], vb[8];
+    const int ld_voff = (int)(((tid >> 5) * ld + (tid & 31) * 2) * sizeof(TS));       // lane's element pair in rows 0 .. 7
+    const int ld_step = (int)(8 * ld * sizeof(TS));                                    // 8 rows per load
+    auto fetch = [&](int col) {
+        const __amdgpu_buffer_rsrc_t ra = tail_rsrc(tile(xl, col));      // rows of L_{xl,col}: slab rows of X (its columns)
+        const __amdgpu_buffer_rsrc_t rb = tail_rsrc(tile(xi, col));      // rows of L_{xi,col}: lanes of X (its rows)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) va[t] = TailRaw<TS>::load(ra, ld_voff, t * ld_step);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) vb[t] = TailRaw<TS>::load(rb, ld_voff, t * ld_step);
+    };
+    // nc: the column to prefetch under this column's MFMA phase (>= xl: none)
+    auto accumulate = [&](int col, bool fetched, int nc) {
         // (pairs step aside too: with roles by arrival two pairs can share a CU; a pair only accumulates OUTSIDE its own
         // window, so the word it reads never counts itself)
         unsigned bz = 0u;
         if (busy != nullptr && tid == 0) bz = tail_ld32(busy);
-        tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
-        tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
+        if constexpr (PRE) {
+            if (!fetched) fetch(col);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int row = 8 * t + (tid >> 5), c2 = (tid & 31) * 2;
+                *reinterpret_cast<d2_t*>(&sh.Ld[row][c2]) = TailRaw<TS>::value(va[t]);
+                *reinterpret_cast<d2_t*>(&sh.Ls[row][c2]) = TailRaw<TS>::value(vb[t]);
+            }
+        } else {
+            tail_tile_in(sh.Ld, tile(xl, col), ld, tid);      // rows of L_{xl,col}: slab rows of X (its columns)
+            tail_tile_in(sh.Ls, tile(xi, col), ld, tid);      // rows of L_{xi,col}: lanes of X (its rows)
+        }
         if (tid == 0) sh.park = (int)bz;
         __syncthreads();
         const bool park = busy != nullptr && sh.park != 0;
+        if constexpr (PRE) {
+            if (nc < xl) fetch(nc);
+        }
 #pragma unroll 2
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;
             const d2_t bT = -*reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);   // the update's minus sign, once
+            // ACC16 = number of 16-column blocks accumulated in the 16x16x4 form: A[m][k] = L_{xl,col}[16 b + m][k] from
+            // lane (k = i, m = c), one accumulator per 16 tile columns -- one LDS operand read per 4096 flops where the
+            // 4x4x4 form needs one per 1024 (it replicates every A value over four lanes, and the LDS charges for the
+            // replicas: 1088 LDS cycles against 1024 MFMA cycles per CU and k8 step with two workgroups per CU).  The
+            // 4x4x4 form has the higher MFMA rate (74 vs 49 TF/s back to back): the rest of the blocks stay on it.
+            // Both forms produce the same bits (same k order inside an instruction).
+            if constexpr (ACC16 > 0) {
+                d2_t aB[ACC16];
 #pragma unroll
-            for (int gb = 0; gb < 16; gb += 8) {
-                d2_t aT[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) aT[g] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (gb + g) + ia][ko]);
+                for (int b = 0; b < ACC16; ++b) aB[b] = *reinterpret_cast<const d2_t*>(&sh.Ld[16 * b + c][ko]);
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        X[gb + g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[g][e2], bT[e2], X[gb + g], 0, 0, 0);
+                    for (int b = 0; b < ACC16; ++b)
+                        X4[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[b][e2], bT[e2], X4[b], 0, 0, 0);
+            }
+            if constexpr (ACC16 < 4) {
+                constexpr int G0 = 4 * ACC16, NG = 16 - G0;
+                d2_t aT[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) aT[g] = *reinterpret_cast<const d2_t*>(&sh.Ld[4 * (G0 + g) + ia][ko]);
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        XG(G0 + g) = __builtin_amdgcn_mfma_f64_4x4x4f64(aT[g][e2], bT[e2], XG(G0 + g), 0, 0, 0);
             }
             if (pair) {     // rows of L_{tl,col} are in Ls
                 d2_t bD[4], aD[4];
@@ -368,38 +448,64 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     };
 
     // ---------------- left-looking accumulation: first the H history columns to the left of this launch's columns
-    // (final since an earlier launch: nothing to wait for), then this launch's columns as they are published
-    for (int col = warm ? 0 : -H; col < 0; ++col) {
-        if (zero_tile(xi, col)) continue;
-        if (xl >= 0) accumulate(col);
-        else accumulate_D0(col);
-    }
+    // (final since an earlier launch: nothing to wait for), then this launch's columns as they are published.
     // A tile's column c+1 needs its column c as an operand, so the published columns of a block row form a prefix:
     // instead of polling two flags per column (a 1-2 us L2 round trip each time, even when long set), the 64 lanes of
-    // wave 0 look at the next 64 columns of both operand rows at once and the loop runs through everything that is
-    // ready without polling again; it blocks on a single column only when it has caught up with the producers.
+    // wave 0 look at the next 64 columns of both operand rows at once (ready_prefix) and the loop runs through
+    // everything that is ready without polling again; it blocks on a single column only when it has caught up with
+    // the producers.
     int ready_upto = 0;
-    for (int col = 0; col < xl && alive && !warm; ++col) {
-        if (zero_tile(xi, col)) continue;
-        if (col >= ready_upto) {
-            if (tid < 64) {
-                const int cc = col + tid;
-                const bool ok = cc < xl && tail_ld32(flag(cc, xl)) != 0u && tail_ld32(flag(cc, xi)) != 0u;
-                const unsigned long long m = __ballot(ok);
-                if (tid == 0) sh.ok = (int)__builtin_ctzll(~m);           // leading ready columns (0..64)
-            }
-            __syncthreads();
-            const int nready = sh.ok;
-            __syncthreads();
-            if (nready > 0) {
-                ready_upto = col + nready;
-            } else {
-                alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
-                if (!alive) break;
-                ready_upto = col + 1;
-            }
+    auto ready_prefix = [&](int col) {      // all 256 threads; makes ready_upto > col or clears alive
+        if (tid < 64) {
+            const int cc = col + tid;
+            const bool ok = cc < xl && tail_ld32(flag(cc, xl)) != 0u && tail_ld32(flag(cc, xi)) != 0u;
+            const unsigned long long m = __ballot(ok);
+            if (tid == 0) sh.ok = (int)__builtin_ctzll(~m);           // leading ready columns (0..64)
         }
-        accumulate(col);
+        __syncthreads();
+        const int nready = sh.ok;
+        __syncthreads();
+        if (nready > 0) {
+            ready_upto = col + nready;
+        } else {
+            alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
+            ready_upto = col + 1;
+        }
+    };
+    if constexpr (!PRE) {
+        for (int col = warm ? 0 : -H; col < 0; ++col) {
+            if (zero_tile(xi, col)) continue;
+            if (xl >= 0) accumulate(col, false, xl);
+            else accumulate_D0(col);
+        }
+        for (int col = 0; col < xl && alive && !warm; ++col) {
+            if (zero_tile(xi, col)) continue;
+            if (col >= ready_upto) {
+                ready_prefix(col);
+                if (!alive) break;
+            }
+            accumulate(col, false, xl);
+        }
+    } else {
+        if (xl < 0) {
+            for (int col = warm ? 0 : -H; col < 0; ++col) accumulate_D0(col);
+        }
+        auto next_col = [&](int col) {      // the next column with a non-zero operand tile in row xi (xl: none)
+            do ++col; while (col < xl && zero_tile(xi, col));
+            return col;
+        };
+        bool fetched = false;
+        for (int col = (xl >= 0) ? next_col(-H - 1) : 0; col < xl && alive && !warm;) {
+            if (col >= ready_upto) {        // (only columns >= 0 get here: ready_upto starts at 0)
+                ready_prefix(col);
+                if (!alive) break;
+            }
+            const int nc = next_col(col);
+            const bool pre = nc < xl && nc < ready_upto;       // (history columns: nc < 0 <= ready_upto)
+            accumulate(col, fetched, pre ? nc : xl);
+            fetched = pre;
+            col = nc;
+        }
     }
 
     // ---------------- the off-diagonal tile becomes final: X <- X L_{xl,xl}^-T
@@ -435,18 +541,18 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 const double av = sh.Linv[p][ia][i];
-                const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, X[p], 0.0, 0, 0, 0);
-                X[p] = Y;
+                const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, XG(p), 0.0, 0, 0, 0);
+                XG(p) = Y;
                 const double Yn = -Y;          // one sign flip per step instead of one per multiplier
 #pragma unroll
                 for (int g = p + 1; g < 16; ++g) {
                     const double al = Lout[4 * g + ia][4 * p + i];
-                    X[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, X[g], 0, 0, 0);
+                    XG(g) = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, XG(g), 0, 0, 0);
                 }
             }
             TAIL_STAMP(4);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = X[g];
+            for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = XG(g);
             __syncthreads();
             TAIL_STAMP(9);
             tail_tile_out(tile(xi, xl), ld, sh.Ls, tid);       // stores in flight ...

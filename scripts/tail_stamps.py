@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the tile-DAG kernel's critical chain spends its time: s_memtime stamps of the pair workgroups (development).
 
-    python3 scripts/tail_stamps.py [N]
+    python3 scripts/tail_stamps.py [N] [name=value ...]
 """
 import ctypes, os, sys
 import numpy as np, torch
@@ -10,6 +10,9 @@ import gpmc
 from gpmc import core, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 gpmc.set_option('use_graph', 0)
+for a in sys.argv[2:]:
+    k, v = a.split('=')
+    gpmc.set_option(k, int(v))
 rng = np.random.RandomState(124)
 X = rng.uniform(0, 10, (n, 2)); g = rng.standard_normal(n) * 5
 plan = core.LogMarginalPlan(X, g, 'rbf')
