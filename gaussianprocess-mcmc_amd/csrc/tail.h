@@ -90,34 +90,7 @@ __device__ inline void tail_st_sc1(float* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint((float)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// 64 x 64 tile W -> LDS [row][col] with sc1 loads (bytes another workgroup published in this launch)
-template <typename TS>
-__device__ inline void tail_tile_in(double (*dst)[MP_LD], const TS* __restrict__ src, int ld, int tid) {
-    double v[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int e = tid + 256 * t;
-        v[t] = tail_ld_sc1(src + (size_t)(e >> 6) * ld + (e & 63));
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int e = tid + 256 * t;
-        dst[e >> 6][e & 63] = v[t];
-    }
-}
-
-// LDS [row][col] -> W with write-through stores; tail_drain() + barrier + the flag store follow
-template <typename TS>
-__device__ inline void tail_tile_out(TS* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int e = tid + 256 * t;
-        tail_st_sc1(dst + (size_t)(e >> 6) * ld + (e & 63), src[e >> 6][e & 63]);
-    }
-}
-__device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Operand tiles for the accumulation: two adjacent elements per lane and load (16 bytes of f64, 8 of f32) through a raw
+// Tiles between W and a workgroup: two adjacent elements per lane and access (16 bytes of f64, 8 of f32) through a raw
 // buffer descriptor with the sc1 (agent scope) cache policy -- the same visibility as the sc1 global loads above, but
 // the 8 loads of a tile share ONE per-lane offset register and take their row step from an SGPR, and the loaded bits
 // stay untouched in registers until they are staged (a conversion at load time would wait for the load).
@@ -130,6 +103,9 @@ template <> struct TailRaw<double> {
         return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);      // aux bit 4 = sc1 on gfx94x / gfx950
     }
     __device__ static inline d2_t value(type v) { return __builtin_bit_cast(d2_t, v); }
+    __device__ static inline void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, d2_t v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tail_u4, v), r, voff, soff, 16);
+    }
 };
 template <> struct TailRaw<float> {
     typedef tail_u2 type;
@@ -142,11 +118,43 @@ template <> struct TailRaw<float> {
         o[1] = (double)__uint_as_float(v[1]);
         return o;
     }
+    __device__ static inline void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, d2_t v) {
+        tail_u2 o;
+        o[0] = __float_as_uint((float)v[0]);
+        o[1] = __float_as_uint((float)v[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(o, r, voff, soff, 16);
+    }
 };
 template <typename TS>
 __device__ inline __amdgpu_buffer_rsrc_t tail_rsrc(const TS* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<TS*>(p), 0, 0x7fffffff, 0x00020000);
 }
+
+// 64 x 64 tile W -> LDS [row][col] with sc1 loads (bytes another workgroup published in this launch): 8 loads of 16 (f32
+// storage: 8) bytes per lane -- an 8-byte sc1 access moves 0.54-0.70 of the bytes per time of a 16-byte one, and an
+// 8-byte sc1 STORE takes 2.7 x the time per byte of a 16-byte one (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <typename TS>
+__device__ inline void tail_tile_in(double (*dst)[MP_LD], const TS* __restrict__ src, int ld, int tid) {
+    const __amdgpu_buffer_rsrc_t r = tail_rsrc(src);
+    const int voff = (int)(((tid >> 5) * ld + (tid & 31) * 2) * sizeof(TS)), step = (int)(8 * ld * sizeof(TS));
+    typename TailRaw<TS>::type v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = TailRaw<TS>::load(r, voff + t * step, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *reinterpret_cast<d2_t*>(&dst[8 * t + (tid >> 5)][(tid & 31) * 2]) = TailRaw<TS>::value(v[t]);
+}
+
+// LDS [row][col] -> W with write-through (sc1) stores; tail_drain() + barrier + the flag store follow
+template <typename TS>
+__device__ inline void tail_tile_out(TS* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
+    const __amdgpu_buffer_rsrc_t r = tail_rsrc(dst);
+    const int voff = (int)(((tid >> 5) * ld + (tid & 31) * 2) * sizeof(TS)), step = (int)(8 * ld * sizeof(TS));
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        TailRaw<TS>::store(r, voff + t * step, 0, *reinterpret_cast<const d2_t*>(&src[8 * t + (tid >> 5)][(tid & 31) * 2]));
+}
+__device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 
 // all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
 // acquire = true: the bytes behind the flags were written with PLAIN stores and released (the GEMM's hand-over tiles):
@@ -342,9 +350,9 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
         const __amdgpu_buffer_rsrc_t ra = tail_rsrc(tile(xl, col));      // rows of L_{xl,col}: slab rows of X (its columns)
         const __amdgpu_buffer_rsrc_t rb = tail_rsrc(tile(xi, col));      // rows of L_{xi,col}: lanes of X (its rows)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) va[t] = TailRaw<TS>::load(ra, ld_voff, t * ld_step);
+        for (int t = 0; t < 8; ++t) va[t] = TailRaw<TS>::load(ra, ld_voff + t * ld_step, 0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) vb[t] = TailRaw<TS>::load(rb, ld_voff, t * ld_step);
+        for (int t = 0; t < 8; ++t) vb[t] = TailRaw<TS>::load(rb, ld_voff + t * ld_step, 0);
     };
     // nc: the column to prefetch under this column's MFMA phase (>= xl: none)
     auto accumulate = [&](int col, bool fetched, int nc) {
