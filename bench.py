@@ -435,11 +435,12 @@ def main():
                     'traffic': tr, 'traffic_unit': 'HBM-side bytes per launch (PMC)', 'traffic_source': src,
                     'traffic_measured_in_run': False}
         r_gemm = roof('gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)', 'gpmc::gemm4_nt_kernel',
-                      k_ms, k_launches, k_flops, 'K = 256 rank updates on v_mfma_f64_4x4x4, 128x128 tiles')
+                      k_ms, k_launches, k_flops, 'K = 384 rank updates (outer block of the look-ahead at this size) on v_mfma_f64_4x4x4, 128x128 tiles')
         r_dag = roof('gpmc::tail_kernel (tile-DAG factorisation: look-ahead panels and the last <= 6144 columns)',
                      'gpmc::tail_kernel', d_ms, d_launches, d_flops,
-                     'one launch per panel / tail; bulk on v_mfma_f64_4x4x4 from 64x64 LDS tiles, critical path = the '
-                     'pivot chain (18-20 us per 64 columns); panel launches overlap the GEMM on a second stream, so '
+                     'one launch per panel / tail; bulk on v_mfma_f64_16x16x4 from 64x64 LDS tiles (operands prefetched '
+                     'in the tail launch), critical path = the pivot chain (17-19 us per 64 columns) on '
+                     'v_mfma_f64_4x4x4; panel launches overlap the GEMM on a second stream, so '
                      'kernel_ms_per_step of the two kernels add up to more than the step')
         roofline, roofline_other = (r_dag, r_gemm) if d_ms >= k_ms else (r_gemm, r_dag)
         for r in (roofline, roofline_other):
@@ -458,8 +459,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (no GPU work; plumbing test only)',
             'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
                        'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
-                       'schedule': 'auto (look-ahead: one tile-DAG launch per 256-column panel beside the trailing GEMM while '
-                                   '>4096 columns remain, then one tile-DAG launch for the rest)',
+                       'schedule': 'auto (look-ahead: one tile-DAG launch per 384-column panel beside the trailing GEMM while '
+                                   '>6144 columns remain, then one tile-DAG launch for the rest)',
                        'launch': 'recorded launch sequence (one fork/join hipGraph), replayed',
                        'enqueue': 'pipelined (back to back)' if a.pipelined else 'sync-each (result read before the next step)',
                        'g': 'GP draw chol(K+sn^2 I) z at the truth hyper-parameters (BASELINE.md 2)'},

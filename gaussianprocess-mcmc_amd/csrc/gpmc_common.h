@@ -57,7 +57,8 @@ struct Options {
                               // (N = 8192, ms/eval: 4096 5.20, 5120 5.00, 6144 5.01)
     int tail_whole_m = 7168;  // problems of at most this many columns are ONE tile-DAG launch (7168: 3.91 ms vs 4.17 with a
                               // look-ahead phase in front; 8192: 5.57 vs 5.0)
-    int tail_m_f32 = 4096, tail_whole_m_f32 = 4096;   // the same two extents for float storage
+    int tail_m_f32 = 6144, tail_whole_m_f32 = 6144;   // the same two extents for float storage (16x16x4 accumulation: f32 N = 8192
+                              // 4.25 -> 3.93 ms with 6144 instead of 4096, 16384 19.2 -> 18.85; 5120 4.03, 7168 4.10)
     int tail_warm = 1;        // tile-DAG pairs run the factor once on an identity tile before their real pass (instruction cache, tail.h)
     int tail_roles_by_index = 0;   // measurements only: pairs = blocks 0 .. T-1 (can deadlock into the spin limit when processes share a card)
     int tail_acc16 = 1;       // tile-DAG off-diagonal accumulation on v_mfma_f64_16x16x4 (0: the 4x4x4 form, same bits; tail.h)
@@ -70,6 +71,7 @@ struct Options {
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
     int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the
                               // timeout path -- every wait that is not already satisfied aborts the launch)
+    int la_first_nb = 0;      // width of the first look-ahead panel of the tile-DAG schedule (0 = the outer block)
     int dag_ahead = 1;        // look-ahead: the trailing GEMM hands the next-but-one panel's columns over tile by tile inside its
                               // launch (priority tile columns + flags) instead of at its end
     int dag_wprio = 0;        // wave priority (0-2) of the worker workgroups of a look-ahead panel launch (the pairs run at 3)

@@ -170,6 +170,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "la_first_nb")) g_opt.la_first_nb = value;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
     else if (!strcmp(name, "tail_prefetch_t")) g_opt.tail_prefetch_t = value;
     else if (!strcmp(name, "dag_prefetch")) g_opt.dag_prefetch = value ? 1 : 0;
@@ -220,6 +221,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "la_first_nb")) return g_opt.la_first_nb;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
     if (!strcmp(name, "tail_prefetch_t")) return g_opt.tail_prefetch_t;
     if (!strcmp(name, "dag_prefetch")) return g_opt.dag_prefetch;

@@ -687,9 +687,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (!attr_done) {
             const void* fns[] = {reinterpret_cast<const void*>(tail_kernel<T, 0, false>),
                                  reinterpret_cast<const void*>(tail_kernel<T, 4, false>),
-                                 reinterpret_cast<const void*>(tail_kernel<T, 4, true>)};
+                                 sizeof(T) == 8 ? reinterpret_cast<const void*>(tail_kernel<double, 4, true>) : nullptr};
             for (const void* fn : fns)
-                GPMC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
+                if (fn) GPMC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TailShared)));
             attr_done = true;
         }
         // grid = the Tt pairs + workers for the off-diagonal tiles: at most `workers` of them
@@ -711,10 +711,12 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                            (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags)
         // variants (tail.h): the 4x4x4 accumulation (cross-checks only); the 16x16x4 accumulation; the same with the next
         // column's operands prefetched -- for launches whose time is their bulk, not their pivot chain
-        const bool pre = g_opt.tail_acc16 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)
+        const bool pre = g_opt.tail_acc16 && sizeof(T) == 8 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)
                                                       : g_opt.dag_prefetch != 0);
         if (!g_opt.tail_acc16) GPMC_TAIL_LAUNCH(0, false);
-        else if (pre) GPMC_TAIL_LAUNCH(4, true);
+        else if (pre) {      // (float storage: 8-byte loads, no gain measured -- f32 N = 8192 3.92 with, 3.86 without)
+            if constexpr (sizeof(T) == 8) GPMC_TAIL_LAUNCH(4, true);
+        }
         else GPMC_TAIL_LAUNCH(4, false);
 #undef GPMC_TAIL_LAUNCH
         GPMC_LAUNCH_CHECK();
@@ -787,6 +789,10 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         };
         hipEvent_t pe, ge = nullptr;
         int nbk = la_nb_dag(np_);
+        // the first panel is the only one that runs alone on the chip (its chain, ~18 us per 64 columns, is exposed): it
+        // may be narrower than the rest (la_first_nb; 0 = the same)
+        if (g_opt.outer_nb <= 0 && g_opt.la_first_nb > 0 && g_opt.la_first_nb % 128 == 0 && g_opt.la_first_nb < nbk)
+            nbk = g_opt.la_first_nb;
         if (nbk > np_) nbk = np_;
         // In-launch hand-over (dag_ahead): G_k -- the update of the columns beyond panel k+1 by panel k -- processes the
         // tiles of panel k+2's columns first and flags each one (gemm4.h), and D_{k+2} gates its tiles on those flags

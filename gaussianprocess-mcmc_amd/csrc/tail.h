@@ -382,11 +382,13 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
         for (int k8 = 0; k8 < 8; ++k8) {
             const int ko = 8 * k8 + 2 * i;
             const d2_t bT = -*reinterpret_cast<const d2_t*>(&sh.Ls[16 * w + c][ko]);   // the update's minus sign, once
-            // ACC16 = number of 16-column blocks accumulated in the 16x16x4 form: A[m][k] = L_{xl,col}[16 b + m][k] from
-            // lane (k = i, m = c), one accumulator per 16 tile columns -- one LDS operand read per 4096 flops where the
-            // 4x4x4 form needs one per 1024 (it replicates every A value over four lanes, and the LDS charges for the
-            // replicas: 1088 LDS cycles against 1024 MFMA cycles per CU and k8 step with two workgroups per CU).  The
-            // 4x4x4 form has the higher MFMA rate (74 vs 49 TF/s back to back): the rest of the blocks stay on it.
+            // ACC16 = number of 16-column blocks accumulated in the 16x16x4 form (4 = all, the default; 0 = none, kept
+            // for cross-checks): A[m][k] = L_{xl,col}[16 b + m][k] from lane (k = i, m = c), one accumulator per 16 tile
+            // columns -- one LDS operand read per 4096 flops where the 4x4x4 form needs one per 1024 (it replicates every
+            // A value over four lanes, and the LDS charges for the replicas: 1088 LDS cycles against 1024 MFMA cycles
+            // per CU and k8 step with two workgroups per CU).  The 4x4x4 instruction has the higher rate (74 vs 49 TF/s
+            // back to back), but a mix loses to all-16x16x4 with and without prefetch (N = 8192: 2 blocks 4.47 ms,
+            // 3 blocks 4.50, 4 blocks 4.35; 7168: 3.28 / 3.26 / 3.07): fewer instructions win.
             // Both forms produce the same bits (same k order inside an instruction).
             if constexpr (ACC16 > 0) {
                 d2_t aB[ACC16];
