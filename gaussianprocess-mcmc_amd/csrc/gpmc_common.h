@@ -66,7 +66,8 @@ struct Options {
                               // operands under the MFMA phase (0 = never; needs tail_acc16)
     int dag_prefetch = 0;     // ... look-ahead panel launches too (8192: +-0, 9216: -0.9 %, 12288: +2 %)
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
-    int tail_workers = 480;   // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column)
+    int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);
+                              // 0 = auto by the launch's bulk-to-chain ratio (potrf.hip, alone_workers: 256 - T, 256 or 480)
     int dag_workers = 0;      // ... of one that factors a look-ahead panel beside the trailing GEMM; 0 = auto: half the panel width
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
     int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the

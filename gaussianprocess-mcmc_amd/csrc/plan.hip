@@ -168,7 +168,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_ahead")) g_opt.dag_ahead = value ? 1 : 0;
     else if (!strcmp(name, "tail_spin_limit")) g_opt.tail_spin_limit = value < 0 ? 0 : value;
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 1 ? 1 : value;
+    else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
     else if (!strcmp(name, "la_first_nb")) g_opt.la_first_nb = value;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;

@@ -723,11 +723,28 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (g_prof.on) return prof_mark2(st);
         return 0;
     };
+    // Worker workgroups of a tile-DAG launch that has the chip to itself (tail_workers > 0 overrides).  A launch whose time
+    // is its pivot chain does best when every pair has a CU to itself -- a co-resident worker's MFMA stream slows the
+    // pair's factor wave even with the parking (tail.h) -- i.e. pairs + workers <= 256 workgroups; a launch whose time is
+    // its bulk wants every CU slot filled (2 per CU).  ms/eval over workers (f64, whole problem):
+    // N = 2048: 128 0.575, 192 0.577, 256 0.606, 480 0.614;  3072: 128 0.859, 192 0.845, 256 0.894, 480 0.899;
+    // 4096: 192 1.193, 256 1.176, 480 1.186;  5120: 256 1.70, 384 1.64, 480 1.56;  6144: 384 2.36, 480 2.15.
+    // Decided by the launch's bulk time (its flops at the ~33 TF/s the workers reach) against its chain (~17.5 us per tile
+    // column): the sizes above sit at 0.15 / 0.35 / 0.62 / 0.97 / 1.4.
+    auto alone_workers = [&](int k0, int Tt, int mp_rows, int Hh) {
+        if (g_opt.tail_workers > 0) return g_opt.tail_workers;
+        const double m = 64.0 * Tt, below = (double)(mp_rows - k0) - m, K = 64.0 * Hh;
+        const double flops = 2.0 * K * (0.5 * m * m + below * m) + m * m * m / 3.0 + below * m * m;
+        const double ratio = (flops / 33e12) / (Tt * 17.5e-6);
+        if (ratio < 0.42 && Tt <= 160) return 256 - Tt < 96 ? 96 : 256 - Tt;
+        if (ratio < 0.85) return 256;
+        return 480;
+    };
     auto tail_from = [&](int k0) -> int {
         int rc = final_flush();     // whatever the last panel launch parked must be in W before tiles are read
         if (rc) return rc;
         pk = Parked();
-        return dag_launch(k0, (np_ - k0) / NB_IN, mp, 0, s, g_opt.tail_workers);
+        return dag_launch(k0, (np_ - k0) / NB_IN, mp, 0, s, alone_workers(k0, (np_ - k0) / NB_IN, mp, 0));
     };
     if (g_opt.lookahead < 0 && use_tail(0)) la = false;      // the whole problem is one tile-DAG launch
     // look-ahead hands over to the tail once the tile-DAG launch can take the rest (else: once < la_min_m columns remain)
@@ -779,12 +796,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         auto la_nb_dag = [&](int rem) {
             if (g_opt.outer_nb > 0) return NB;
             (void)rem;                       // by problem size: switching 512 -> 384 below 9216 remaining columns
-            return np_ >= 9216 ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
+            // (with the 16x16x4 accumulation NB 512 also wins below 9216 columns: N = 8192 NB 384 / 192 workers 4.36,
+            //  NB 512 with 192 / 224 / 256 / 288 workers 4.31 / 4.31 / 4.28 / 4.29)
+            return (np_ >= 9216 || g_opt.tail_acc16) ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
         };
         auto panel_workers = [&](int nb, int rem) {
             if (g_opt.dag_workers > 0) return g_opt.dag_workers;
             (void)rem;   // by problem size too: more workers as the remaining columns shrink loses (12288: 13.54 vs 12.95)
-            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : 224);
+            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : (np_ >= 9216 ? 224 : 256));
             return nb / 2;
         };
         hipEvent_t pe, ge = nullptr;
@@ -830,7 +849,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (rc) return rc;
             rc = sc->edge_wait(ps, ef);
             if (rc) return rc;
-            rc = dag_launch(0, nbk / NB_IN, mp, 0, ps, g_opt.tail_workers);
+            rc = dag_launch(0, nbk / NB_IN, mp, 0, ps, alone_workers(0, nbk / NB_IN, mp, 0));
             if (rc) return rc;
             rc = sc->edge_record(ps, &pe);
             if (rc) return rc;
@@ -842,7 +861,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (hand_over(k1)) {
                 rc = sc->edge_wait(s, pe);
                 if (rc) return rc;
-                return dag_launch(k1, (np_ - k1) / NB_IN, mp, nbk / NB_IN, s, g_opt.tail_workers);
+                return dag_launch(k1, (np_ - k1) / NB_IN, mp, nbk / NB_IN, s, alone_workers(k1, (np_ - k1) / NB_IN, mp, nbk / NB_IN));
             }
             const int nbn = (np_ - k1 < la_nb_dag(np_ - k1)) ? np_ - k1 : la_nb_dag(np_ - k1);
             const int k2 = k1 + nbn;
