@@ -295,6 +295,9 @@ def main():
     else:
         import gpmc
         from gpmc import _lib, core
+        for kv in filter(None, os.environ.get('GPMC_BENCH_OPTS', '').split(',')):     # development: library options for this run
+            k, v = kv.split('=')
+            gpmc.set_option(k, int(v))
         X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank, threads=threads)
         plan = core.LogMarginalPlan(X, g, 'rbf')   # default path: the launch sequence recorded once, replayed per step
 

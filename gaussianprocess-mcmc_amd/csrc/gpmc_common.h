@@ -72,7 +72,6 @@ struct Options {
                               // (N = 8192, NB 256: 32 workers 9.16 ms, 64 6.42, 96 5.63, 128 5.38, 192 5.48, 480 6.35)
     int tail_spin_limit = 1 << 20;   // polls a waiting tile-DAG workgroup makes before it gives up (test hook: 0 forces the
                               // timeout path -- every wait that is not already satisfied aborts the launch)
-    int la_first_nb = 0;      // width of the first look-ahead panel of the tile-DAG schedule (0 = the outer block)
     int dag_ahead = 1;        // look-ahead: the trailing GEMM hands the next-but-one panel's columns over tile by tile inside its
                               // launch (priority tile columns + flags) instead of at its end
     int dag_wprio = 0;        // wave priority (0-2) of the worker workgroups of a look-ahead panel launch (the pairs run at 3)
@@ -153,14 +152,25 @@ extern unsigned long long* g_tail_dbg;   // diagnostic stamp buffer of the tail 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---------------------------------------------------------------- internal entry points
+// housekeeping a kernel-build launch can carry for the log-marginal plan (kbuild.hip): copy a vector, clear a word
+template <typename T>
+struct KbuildExtras {
+    const T* vec_src = nullptr;
+    T* vec_dst = nullptr;
+    int vec_n = 0;
+    int* zero_word = nullptr;
+};
 template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
-           int rows_out, int cols_out, int ldk, int flags, hipStream_t s);
+           int rows_out, int cols_out, int ldk, int flags, hipStream_t s, KbuildExtras<T> ex = KbuildExtras<T>());
 struct Sched;
 template <typename T>
 int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0, Sched* sc = nullptr);
+// host_base / slot_dev (both or neither): the four results also go straight to pinned host memory, 4 doubles at
+// host_base + 4 * (int)*slot_dev, so that no copy has to follow the reduction
 template <typename T>
-int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s);
+int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s,
+                double* host_base = nullptr, const T* slot_dev = nullptr);
 template <typename T>
 int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s);
 template <typename T>
@@ -222,6 +232,7 @@ struct Sched {
     size_t ev_next = 0;
     std::vector<SeqOp> ops;
     bool cap_main = false, cap_panel = false;
+    bool info_cleared = false;           // the caller has already cleared *info_dev on the main stream (potrf skips its memset)
 
     int init(hipStream_t main_stream);                       // creates the panel stream and a first batch of events
     int reserve_events(size_t n);

@@ -33,9 +33,16 @@ template <typename T, int KERNEL>
 __global__ void __launch_bounds__(256)
 kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restrict__ Z, int nz, int ldz,
               const T* __restrict__ hyp, T* __restrict__ K, int rows_out, int cols_out, int ldk, int flags,
-              int same_xz, int vec_ok) {
+              int same_xz, int vec_ok, KbuildExtras<T> ex) {
     const int row0 = blockIdx.y * KB_ROWS;
     const int col0 = blockIdx.x * KB_COLS;
+    // the log-marginal plan's per-evaluation housekeeping rides on workgroup (0, 0) instead of taking launches of its
+    // own (a copy and a fill kernel of ~5 us each, 2 % of an N = 2048 evaluation): the right-hand side goes into its
+    // riding row below the matrix, the factorisation's info word is cleared
+    if (ex.vec_dst != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int e = threadIdx.x; e < ex.vec_n; e += 256) ex.vec_dst[e] = ex.vec_src[e];
+        if (threadIdx.x == 0 && ex.zero_word != nullptr) *ex.zero_word = 0;
+    }
     if ((flags & GPMC_KB_LOWER) && col0 > row0 + KB_ROWS - 1) return;  // tile strictly above the diagonal
 
     __shared__ T xi[KB_ROWS][KB_DC];
@@ -121,7 +128,7 @@ kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restric
 
 template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
-           int rows_out, int cols_out, int ldk, int flags, hipStream_t s) {
+           int rows_out, int cols_out, int ldk, int flags, hipStream_t s, KbuildExtras<T> ex) {
     GPMC_ARG(kernel == GPMC_KERNEL_RBF || kernel == GPMC_KERNEL_MATERN52_ARD, 1);
     GPMC_ARG(X != nullptr, 2);
     GPMC_ARG(n > 0 && d > 0 && ldx >= d, 3);
@@ -134,17 +141,17 @@ int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, in
     dim3 grid((cols_out + KB_COLS - 1) / KB_COLS, (rows_out + KB_ROWS - 1) / KB_ROWS);
     if (kernel == GPMC_KERNEL_RBF)
         hipLaunchKernelGGL((kbuild_kernel<T, GPMC_KERNEL_RBF>), grid, dim3(256), 0, s, X, n, d, ldx, Z, nz, ldz,
-                           hyp_dev, K, rows_out, cols_out, ldk, flags, same, vec_ok);
+                           hyp_dev, K, rows_out, cols_out, ldk, flags, same, vec_ok, ex);
     else
         hipLaunchKernelGGL((kbuild_kernel<T, GPMC_KERNEL_MATERN52_ARD>), grid, dim3(256), 0, s, X, n, d, ldx, Z,
-                           nz, ldz, hyp_dev, K, rows_out, cols_out, ldk, flags, same, vec_ok);
+                           nz, ldz, hyp_dev, K, rows_out, cols_out, ldk, flags, same, vec_ok, ex);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
 
 template int kbuild<double>(int, const double*, int, int, int, const double*, int, int, const double*, double*, int,
-                            int, int, int, hipStream_t);
+                            int, int, int, hipStream_t, KbuildExtras<double>);
 template int kbuild<float>(int, const float*, int, int, int, const float*, int, int, const float*, float*, int, int,
-                           int, int, hipStream_t);
+                           int, int, hipStream_t, KbuildExtras<float>);
 
 }  // namespace gpmc

@@ -32,7 +32,7 @@ static PlanLayout plan_layout(int n, int d, int es) {
     L.off_W = take((size_t)L.mp * L.ld * es);
     L.off_X = take((size_t)n * d * es);
     L.off_g = take((size_t)n * es);
-    L.off_hyp = take((size_t)(2 + PLAN_MAXD) * es);
+    L.off_hyp = take((size_t)(2 + PLAN_MAXD + 1) * es);      // parameters + the result slot's index
     L.off_out = take(4 * sizeof(double));
     L.off_info = take(sizeof(int));
     L.off_scratch = take(potrf_scratch_bytes(L.np_));
@@ -49,6 +49,7 @@ struct gpmc_plan {
     hipStream_t stream;
     double* host_pin;     // PLAN_SLOTS x (2+MAXD) staged parameters (as T bytes) + PLAN_SLOTS x 4 results
     size_t hyp_slot_bytes;
+    double* host_res_dev; // device address of the pinned results (PLAN_SLOTS x 4 doubles)
     gpmc::Sched sched;    // the plan's own panel stream, events and recorded launch sequence
     bool recorded;
     hipEvent_t ev0, ev1;  // timing of the eager first evaluation and of the first replay (see record_sequence)
@@ -71,13 +72,21 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
     const T* hyp = reinterpret_cast<const T*>(p->ws + L.off_hyp);
     double* out = reinterpret_cast<double*>(p->ws + L.off_out);
     int* info = reinterpret_cast<int*>(p->ws + L.off_info);
+    // the kernel build also puts g into its riding row and clears info (no copy / fill launches of their own), and the
+    // reduction writes the result into the pinned slot whose index travelled with the parameters (no copy after it)
+    KbuildExtras<T> ex;
+    ex.vec_src = g;
+    ex.vec_dst = W + (size_t)L.np_ * L.ld;
+    ex.vec_n = p->n;
+    ex.zero_word = info;
     int rc = kbuild<T>(p->kernel, X, p->n, p->d, p->d, nullptr, 0, 0, hyp, W, L.np_, L.np_, L.ld,
-                       GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s);
+                       GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s, ex);
     if (rc) return rc;
-    GPMC_HIP(hipMemcpyAsync(W + (size_t)L.np_ * L.ld, g, (size_t)p->n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    p->sched.info_cleared = true;
     rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched);
+    p->sched.info_cleared = false;
     if (rc) return rc;
-    return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s);
+    return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s, p->host_res_dev, hyp + (2 + PLAN_MAXD));
 }
 
 static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
@@ -170,7 +179,6 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
-    else if (!strcmp(name, "la_first_nb")) g_opt.la_first_nb = value;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
     else if (!strcmp(name, "tail_prefetch_t")) g_opt.tail_prefetch_t = value;
     else if (!strcmp(name, "dag_prefetch")) g_opt.dag_prefetch = value ? 1 : 0;
@@ -221,7 +229,6 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
-    if (!strcmp(name, "la_first_nb")) return g_opt.la_first_nb;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
     if (!strcmp(name, "tail_prefetch_t")) return g_opt.tail_prefetch_t;
     if (!strcmp(name, "dag_prefetch")) return g_opt.dag_prefetch;
@@ -361,10 +368,16 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
         if (!rc) rc = p->sched.reserve_events((size_t)(2 * (L.np_ / GPMC_PAD) + 8));
         if (rc) { (void)p->sched.destroy(); delete p; return rc; }
     }
-    p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD) * sizeof(double);
+    p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD + 1) * sizeof(double);
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p->host_pin),
                                  PLAN_SLOTS * (p->hyp_slot_bytes + 4 * sizeof(double)), hipHostMallocDefault);
     if (e != hipSuccess) { (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    {   // the reduction kernel writes each result straight into its pinned slot
+        void* dres = nullptr;
+        e = hipHostGetDevicePointer(&dres, reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+        p->host_res_dev = reinterpret_cast<double*>(dres);
+    }
     // zero the riding rows once: only row np_ is ever rewritten (with g), the others stay zero
     e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
                        (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
@@ -394,13 +407,18 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     if (p->slot_busy[slot])
         return fail(-4, "gpmc_plan_logml_async: slot %d still has an evaluation in flight (call gpmc_plan_result first)", slot);
     char* hslot = reinterpret_cast<char*>(p->host_pin) + (size_t)slot * p->hyp_slot_bytes;
+    // staged: the parameters, then (at element 2 + PLAN_MAXD) the index of the result slot, which the reduction kernel
+    // reads back to find where in pinned memory this evaluation's result belongs -- ONE copy carries both
     if (p->es == 8) {
-        memcpy(hslot, kparams_host, (size_t)nk * sizeof(double));
+        double* d = reinterpret_cast<double*>(hslot);
+        memcpy(d, kparams_host, (size_t)nk * sizeof(double));
+        d[2 + PLAN_MAXD] = (double)slot;
     } else {
         float* f = reinterpret_cast<float*>(hslot);
         for (int i = 0; i < nk; ++i) f[i] = (float)kparams_host[i];
+        f[2 + PLAN_MAXD] = (float)slot;
     }
-    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)nk * p->es, hipMemcpyHostToDevice, p->stream));
+    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)(2 + PLAN_MAXD + 1) * p->es, hipMemcpyHostToDevice, p->stream));
     int rc = 0;
     const bool graph_ok = g_opt.use_graph && p->stream != nullptr;   // the NULL stream cannot be captured
     if (!graph_ok || p->evals == 0) {
@@ -428,8 +446,7 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     }
     p->evals++;
     p->slot_busy[slot] = 1;
-    double* hres = reinterpret_cast<double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
-    GPMC_HIP(hipMemcpyAsync(hres, p->ws + p->L.off_out, 4 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    // (no result copy: the reduction kernel has written the pinned slot itself)
     if (!p->slot_ev[slot]) GPMC_HIP(hipEventCreateWithFlags(&p->slot_ev[slot], hipEventDisableTiming));
     GPMC_HIP(hipEventRecord(p->slot_ev[slot], p->stream));
     return 0;

@@ -654,7 +654,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     const int la_pad = (np_ >= 8192) ? 0 : 16000;
     const int pad_serial = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
     const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
-    GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    if (!(sc && sc->info_cleared)) GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
 
     // the last columns as one tile-DAG launch (tail.h): f64
     // (float storage: the kernel converts on load / store, its arithmetic is f64 as in the panel kernels; the f32 trailing
@@ -796,22 +796,22 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         auto la_nb_dag = [&](int rem) {
             if (g_opt.outer_nb > 0) return NB;
             (void)rem;                       // by problem size: switching 512 -> 384 below 9216 remaining columns
-            // (with the 16x16x4 accumulation NB 512 also wins below 9216 columns: N = 8192 NB 384 / 192 workers 4.36,
-            //  NB 512 with 192 / 224 / 256 / 288 workers 4.31 / 4.31 / 4.28 / 4.29)
-            return (np_ >= 9216 || g_opt.tail_acc16) ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
+            // (with the 16x16x4 accumulation NB 512 would also win below 9216 columns when a process has the card to
+            //  itself -- N = 8192: NB 384 / 192 workers 4.36 ms, NB 512 with 192 / 224 / 256 / 288 workers 4.31 / 4.31 / 4.28 /
+            //  4.29 -- but with TWO processes on one card that schedule ended in the tile-DAG spin limit in 13 of 24 runs
+            //  (0 of 4 with NB 384, the schedule the 42 earlier two-process rehearsals ran): not adopted)
+            return np_ >= 9216 ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
         };
         auto panel_workers = [&](int nb, int rem) {
             if (g_opt.dag_workers > 0) return g_opt.dag_workers;
             (void)rem;   // by problem size too: more workers as the remaining columns shrink loses (12288: 13.54 vs 12.95)
-            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : (np_ >= 9216 ? 224 : 256));
+            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : 224);
             return nb / 2;
         };
         hipEvent_t pe, ge = nullptr;
         int nbk = la_nb_dag(np_);
-        // the first panel is the only one that runs alone on the chip (its chain, ~18 us per 64 columns, is exposed): it
-        // may be narrower than the rest (la_first_nb; 0 = the same)
-        if (g_opt.outer_nb <= 0 && g_opt.la_first_nb > 0 && g_opt.la_first_nb % 128 == 0 && g_opt.la_first_nb < nbk)
-            nbk = g_opt.la_first_nb;
+        // (a narrower FIRST panel -- the only one that runs alone on the chip, its chain exposed -- measured +-0 at N = 8192,
+        //  9216 and 12288 with widths 128 / 256, and mixed widths are not something the in-launch hand-over supports)
         if (nbk > np_) nbk = np_;
         // In-launch hand-over (dag_ahead): G_k -- the update of the columns beyond panel k+1 by panel k -- processes the
         // tiles of panel k+2's columns first and flags each one (gemm4.h), and D_{k+2} gates its tiles on those flags

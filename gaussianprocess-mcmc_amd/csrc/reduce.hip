@@ -9,7 +9,8 @@ namespace gpmc {
 template <typename T>
 __global__ void __launch_bounds__(1024)
 logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ alpha,
-                   const int* __restrict__ info, double* __restrict__ out) {
+                   const int* __restrict__ info, double* __restrict__ out, double* __restrict__ host_base,
+                   const T* __restrict__ slot_dev) {
     __shared__ double s_ld[1024], s_q[1024];
     const int tid = threadIdx.x;
     double ld = 0.0, qd = 0.0;
@@ -34,15 +35,22 @@ logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict_
         out[1] = s_ld[0];
         out[2] = s_q[0];
         out[3] = info ? (double)info[0] : 0.0;
+        if (host_base != nullptr) {      // pinned, device-mapped: visible to the host once this kernel has completed
+            double* h = host_base + 4 * (int)slot_dev[0];
+            for (int j = 0; j < 4; ++j) h[j] = out[j];
+            __threadfence_system();
+        }
     }
 }
 
 template <typename T>
-int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s) {
+int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s,
+                double* host_base, const T* slot_dev) {
     GPMC_ARG(W && n > 0 && ldw >= n, 1);
     GPMC_ARG(alpha != nullptr, 4);
     GPMC_ARG(out_dev != nullptr, 6);
-    hipLaunchKernelGGL((logdet_quad_kernel<T>), dim3(1), dim3(1024), 0, s, W, n, ldw, alpha, info_dev, out_dev);
+    hipLaunchKernelGGL((logdet_quad_kernel<T>), dim3(1), dim3(1024), 0, s, W, n, ldw, alpha, info_dev, out_dev,
+                       (host_base != nullptr && slot_dev != nullptr) ? host_base : nullptr, slot_dev);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
@@ -220,7 +228,7 @@ int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStr
 }
 
 #define INST(T)                                                                                              \
-    template int logdet_quad<T>(const T*, int, int, const T*, const int*, double*, hipStream_t);             \
+    template int logdet_quad<T>(const T*, int, int, const T*, const int*, double*, hipStream_t, double*, const T*);             \
     template int pack_lower<T>(const T*, int, int, T, T*, int, int, hipStream_t);                            \
     template int pack_rows<T>(const T*, int, int, int, T*, int, int, int, hipStream_t);                      \
     template int unpack_lower<T>(const T*, int, int, T*, int, int, hipStream_t);                             \

@@ -24,6 +24,12 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world == 1:
         return 0, 1
+    if dev is not None and int(os.environ.get('LOCAL_WORLD_SIZE', world)) > torch.cuda.device_count():
+        # several ranks share one card (rehearsals on a one-GPU box): the look-ahead with 512-column panels can run two
+        # processes into the tile-DAG kernel's spin limit there (2 of 4 runs at N = 9216; 384-column panels: 0 of 52
+        # at N = 8192) -- keep the narrower outer block.  A rank with a card to itself is not affected.
+        from . import _lib
+        _lib.set_option('outer_nb', 384)
     if not dist.is_initialized():
         if backend is None:   # GPMC_DIST_BACKEND=gloo: rehearse several ranks on one GPU (RCCL wants one device per rank)
             backend = os.environ.get('GPMC_DIST_BACKEND') or ('nccl' if dev is not None else 'gloo')

@@ -222,7 +222,7 @@ int gpmc_profile_read(double* out6);
  * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "tail_park", "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
  * "tail_acc16" (1: off-diagonal accumulation on v_mfma_f64_16x16x4; 0: the 4x4x4 form, same bits), "tail_prefetch_t" (tail /
  * whole launches of at least this many tile columns prefetch the next column's operands; 0 = never), "dag_prefetch",
- * "la_first_nb" (width of the first look-ahead panel, 0 = the outer block), "replay_form"; alternative kernels
+ * "replay_form"; alternative kernels
  * "gemm_impl", "gemm_persistent", "gemm_small_bk32", "gemm_8wave", "gemm_xcd_map", "gemm_desync", "panel_impl",
  * "diag_impl".  Unknown names return an error. */
 int gpmc_set_option(const char* name, int value);
