@@ -798,7 +798,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             (void)rem;                       // by problem size: switching 512 -> 384 below 9216 remaining columns
             // (with the 16x16x4 accumulation NB 512 would also win below 9216 columns when a process has the card to
             //  itself -- N = 8192: NB 384 / 192 workers 4.36 ms, NB 512 with 192 / 224 / 256 / 288 workers 4.31 / 4.31 / 4.28 /
-            //  4.29 -- but with TWO processes on one card that schedule ended in the tile-DAG spin limit in 13 of 24 runs
+            //  4.29 -- but with TWO processes on one card that schedule ended in the tile-DAG spin limit in 14 of 24 runs
             //  (0 of 4 with NB 384, the schedule the 42 earlier two-process rehearsals ran): not adopted)
             return np_ >= 9216 ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
         };

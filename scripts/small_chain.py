@@ -7,7 +7,12 @@ sys.path.insert(0, os.path.join(R, 'gaussianprocess-mcmc_amd')); sys.path.insert
 from gpmc import framework
 from oracle import sds_ref
 iters = 30
-for n in [int(a) for a in sys.argv[1:]] or [200, 455, 1024, 2048]:
+import gpmc
+for a in sys.argv[1:]:
+    if '=' in a:
+        k, v = a.split('=')
+        gpmc.set_option(k, int(v))
+for n in [int(a) for a in sys.argv[1:] if a.isdigit()] or [200, 455, 1024, 2048]:
     x, y = sds_ref.synthetic_demo_data(n=n, seed=124)
     y = np.clip(y, 1., 99.)
     np.random.seed(5); framework.run_chain(x, y, 2, framework.DEMO_HYP0)
