@@ -36,6 +36,13 @@
 //   instruction on, so they are zeroed by a memset node: every launch of a factorisation has its own sync region and
 //   ONE memset in front of the whole factorisation zeroes them all (a memset in front of each launch delays it by
 //   5-10 us, enough for a concurrently launched GEMM to take every CU slot first).
+// * Two MFMA shapes.  The pivot chain (64 x 64 factor, TRSM, the pair's diagonal update) runs on v_mfma_f64_4x4x4; the
+//   off-diagonal accumulation -- the bulk of a large launch -- on v_mfma_f64_16x16x4 (template parameter ACC16 = 4),
+//   which needs a quarter of the LDS operand reads per flop; the accumulator registers are the same slabs in both
+//   shapes and the sums have the same bits.  PRE = true additionally prefetches the next column's operand tiles under
+//   the MFMA phase (launches whose time is their bulk; it costs the chain ~3 %, so the host picks per launch).
+// * Tiles move between W and a workgroup as 16-byte sc1 buffer accesses (TailRaw): the guide's visibility table has
+//   them as measured-valid for this hand-off, and an 8-byte sc1 store costs 2.7 x the time per byte.
 #pragma once
 #include "panel_fused.h"
 
