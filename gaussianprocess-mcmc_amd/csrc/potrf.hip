@@ -681,7 +681,11 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (!sync_zeroed) sync_next = 0;
         if ((sync_next + words) * sizeof(unsigned) > TAIL_SYNC_BYTES) return fail(-1, "potrf: sync region overflow");
         unsigned* sync = dag_sync + sync_next;
-        if (!sync_zeroed) GPMC_HIP(hipMemsetAsync(sync, 0, words * sizeof(unsigned), st));
+        if (!sync_zeroed) {     // (rounded up to 1 KiB inside the reserve: the runtime splits an odd-sized fill into two kernels)
+            size_t zb = (words * sizeof(unsigned) + 1023) & ~(size_t)1023;
+            if ((sync_next * sizeof(unsigned)) + zb > TAIL_SYNC_BYTES) zb = words * sizeof(unsigned);
+            GPMC_HIP(hipMemsetAsync(sync, 0, zb, st));
+        }
         sync_next += words;
         static bool attr_done = false;   // per T instantiation
         if (!attr_done) {
@@ -839,7 +843,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 k0 = k1;
             }
             if (total * sizeof(unsigned) <= TAIL_SYNC_BYTES) {
-                GPMC_HIP(hipMemsetAsync(dag_sync, 0, total * sizeof(unsigned), s));
+                size_t zb = (total * sizeof(unsigned) + 1023) & ~(size_t)1023;      // (one fill kernel instead of two)
+                if (zb > TAIL_SYNC_BYTES) zb = total * sizeof(unsigned);
+                GPMC_HIP(hipMemsetAsync(dag_sync, 0, zb, s));
                 sync_zeroed = true;
             }
         }
