@@ -233,6 +233,82 @@ class StubPlan(object):
         pass
 
 
+def device_gp_draw(X, kernel, truth, seed):
+    """g = chol(K(truth) + sn^2 I) z formed on the device with the library's own f64 kernels (bench INPUT for the extra
+    configs: at N = 16384 the host Cholesky of synth_inputs would take most of a minute).  truth = (ell.., sf, sn)."""
+    import torch
+    from gpmc import covK, ops
+    n = X.shape[0]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    Xd = torch.as_tensor(X, dtype=torch.float64).to(dev)
+    kobj, sn = covK.kernel_from_hyp(truth, kernel, torch.float64)
+    kp = kobj.kparams()
+    kp[1] = sn * sn
+    np_ = ops.pad(n)
+    W = torch.zeros((np_ + ops.PAD, np_), dtype=torch.float64, device=dev)
+    ops.kbuild(kernel, Xd, torch.as_tensor(kp, dtype=torch.float64).to(dev), W, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.potrf(W, np_ + ops.PAD, np_, info, ops.potrf_scratch(np_, dev))
+    if int(info.item()) != 0:
+        raise SystemExit('device_gp_draw: truth kernel matrix not positive definite (info=%d)' % int(info.item()))
+    z = torch.as_tensor(np.random.RandomState(seed).standard_normal(n)).to(dev)
+    g = torch.empty(n, dtype=torch.float64, device=dev)
+    ops.trmv_lower(W, n, z, None, g)
+    return g.cpu().numpy()
+
+
+def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
+    """One of BASELINE.json's other configs at its per-GPU size: ms per log-marginal evaluation (sync-each, like the
+    headline), TF/s of N^3/3 and the fraction of the dtype's matrix peak.  f32: the same evaluation in f64 beside it and
+    the stated tolerance |f32 - f64| <= 2e-4 |f64| asserted (tests/test_gpu_kernels.py::test_config5_shape_f32_vs_f64)."""
+    import torch
+    from gpmc import core
+    rng = np.random.RandomState(124)
+    X = rng.uniform(0., 10., (n, d))
+    if kernel == 'rbf':
+        truth = np.array([1.0, 10.0, 1.2])
+        pts = [np.array([1.3, 8.0, 1.0]), np.array([0.8, 12.0, 1.5]), np.array([2.0, 9.0, 0.9]), np.array([1.0, 10.0, 1.2])]
+    else:
+        ell = rng.uniform(0.5, 2.0, d)                                  # SURVEY.md 8(d): ell_k ~ U(0.5, 2)
+        truth = np.concatenate([ell * 3.0, [10.0, 1.2]])
+        pts = [np.concatenate([ell * s, [sf, sn]]) for s, sf, sn in ((3.0, 10.0, 1.2), (2.5, 8.0, 1.0), (3.5, 12.0, 1.5))]
+    g = device_gp_draw(X, kernel, truth, 7)
+    dt = torch.float32 if dtype_name == 'f32' else torch.float64
+    plan = core.LogMarginalPlan(X, g, kernel, dtype=dt)
+    vals = [plan(p) for p in pts]                                       # eager, eager, record (+ replay)
+    plan(pts[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        plan.eval_async(pts[i % len(pts)], 0)
+        r = plan.result(0)
+        if r[3] != 0:
+            raise SystemExit('%s: factorisation reported info=%d' % (name, r[3]))
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    plan.close()
+    peak = 157.3 if dtype_name == 'f32' else FP64_MATRIX_PEAK_TF
+    tf = n ** 3 / 3.0 / (ms * 1e-3) / 1e12
+    out = {'workload': '%s, N=%d, d=%d, %s' % ('RBF' if kernel == 'rbf' else 'ARD Matern-5/2', n, d, dtype_name),
+           'ms_per_eval': ms, 'evals_per_s': 1e3 / ms, 'steps': steps, 'tflops': tf, 'peak_tflops': peak, 'frac_of_peak': tf / peak}
+    if dtype_name == 'f32':
+        p64 = core.LogMarginalPlan(X, g, kernel, dtype=torch.float64, settle=False)
+        v64 = [p64(p) for p in pts]
+        p64.close()
+        rel = max(abs(a - b) / abs(b) for a, b in zip(vals, v64))
+        if rel > 2e-4:
+            raise SystemExit('%s: f32 log-marginal differs from f64 by %.3g relative (stated tolerance 2e-4)' % (name, rel))
+        out['f32_vs_f64_rel_err'] = rel
+        out['tolerance'] = 2e-4
+    if check_against_scipy:
+        from oracle import sds_ref                                       # checker only
+        ref = sds_ref.gp_log_marginal(X, g, pts[0], kernel=('rbf' if kernel == 'rbf' else 'matern52ard'))
+        rel = abs(vals[0] - ref) / abs(ref)
+        if rel > 1e-8:
+            raise SystemExit('%s: parity failure vs SciPy: %r vs %r' % (name, vals[0], ref))
+        out['scipy_rel_err'] = rel
+    return out
+
+
 def timed_steps(plan, pts, steps, pipelined):
     """K steps; returns the last result.  sync-each: read step i before enqueuing i+1.  pipelined: back to back on the
     ring of result slots (a slot is read -- long complete -- before it is re-armed)."""
@@ -263,6 +339,7 @@ def main():
     ap.add_argument('--pipelined', action='store_true', help='time back-to-back enqueues instead of read-each-step')
     ap.add_argument('--no-cpu', action='store_true', help='skip both host baselines')
     ap.add_argument('--no-cpu-ref', action='store_true', help='skip the literal-sequence host baseline (B-ref)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the SDS-proposal and other-config timings of the default run')
     ap.add_argument('--metric-only', action='store_true',
                     help='launch nothing but the metric\'s kernels (for rocprofv3 runs): no host baselines, no extras')
     ap.add_argument('--full', action='store_true', help='= --sds --sds-cpu --chain 10')
@@ -301,10 +378,11 @@ def main():
         X, g, pts = synth_inputs(a.n, a.d, seed=124 + rank, threads=threads)
         plan = core.LogMarginalPlan(X, g, 'rbf')   # default path: the launch sequence recorded once, replayed per step
 
-    nccl = world > 1 and dist.get_backend() == 'nccl'
+    grouped = dist.is_available() and dist.is_initialized()     # world > 1, or one rank with GPMC_FORCE_DIST=1 (RCCL rehearsal)
+    nccl = grouped and dist.get_backend() == 'nccl'
 
     def barrier():
-        if world > 1:
+        if grouped:
             if nccl:
                 dist.barrier(device_ids=[dev.index])
             else:
@@ -320,6 +398,17 @@ def main():
     dt = time.perf_counter() - t0
     if last is not None and last[3] != 0:
         raise SystemExit('factorisation reported info=%d' % last[3])
+
+    # spread: three more blocks of the same K steps (never `value`; the headline block is block 0)
+    block_ms = [1e3 * dt / a.steps]
+    for _ in range(3 if not stub else 0):
+        if dev is not None:
+            torch.cuda.synchronize()
+        tb = time.perf_counter()
+        timed_steps(plan, pts, a.steps, a.pipelined)
+        if dev is not None:
+            torch.cuda.synchronize()
+        block_ms.append(1e3 * (time.perf_counter() - tb) / a.steps)
 
     # the other enqueue form, same K steps (reported beside the headline, never as `value`)
     timed_steps(plan, pts, min(a.warmup, 2), not a.pipelined)
@@ -351,7 +440,7 @@ def main():
         (k_ms, k_launches, k_flops), (d_ms, d_launches, d_flops) = _lib.profile_read()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or (world == 1 and dev is not None)) else 'cpu')
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
 
@@ -391,7 +480,8 @@ def main():
                                       'frac_of_hbm_peak': kb_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         extra['kbuild_lower_only']['note'] = 'writes only the tiles touching the lower triangle; rate quoted against the full s*N^2 bytes'
         del Wk
-    if a.sds and rank == 0 and not stub:
+    default_extras = rank == 0 and world == 1 and not stub and not a.metric_only and not a.no_extras
+    if (a.sds or default_extras) and rank == 0 and not stub:
         from gpmc import sds
         ws = sds.SDSWorkspace(X)
         f = torch.zeros(a.n, dtype=torch.float64, device=dev)
@@ -405,9 +495,24 @@ def main():
             ws.aux_var_model(f, pts[j % len(pts)], gd, need_eta=False)
             ws.propose_f(eta).cpu()
         torch.cuda.synchronize()
-        extra['sds_proposals_per_s'] = reps / (time.perf_counter() - t1)
+        sds_dt = (time.perf_counter() - t1) / reps
+        extra['sds_proposals_per_s'] = 1.0 / sds_dt
         extra['sds_flops_per_proposal'] = 4.0 * a.n ** 3 / 3.0     # inverse form (gpmc/sds.py)
+        sds_tf = 4.0 * a.n ** 3 / 3.0 / sds_dt / 1e12
+        extra['sds_roofline'] = {'bound': 'mfma', 'achieved': sds_tf, 'peak': FP64_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
+                                 'frac': sds_tf / FP64_MATRIX_PEAK_TF, 'proposals': reps,
+                                 'note': 'the reference\'s literal step (sliceSample.py:131-163): K build, chol(K+S) with g and '
+                                         's I riding, R = sI - P P^T, m, chol(R + 1e-11 I), f\' = C eta + m, scalars read back; '
+                                         'includes jitter retries of chol(R) where the point needs them'}
         del ws
+    if default_extras and a.n == 8192 and a.d == 2:
+        # BASELINE.json's other configs at their per-GPU size, a few evaluations each (configs[1], configs[3] per GPU,
+        # configs[4] per GPU)
+        extra['configs'] = {
+            'n2048': time_config('n2048', 2048, 2, 'rbf', 'f64', 40, True),
+            'n4096': time_config('n4096', 4096, 2, 'rbf', 'f64', 30, True),
+            'n16384_f32': time_config('n16384_f32', 16384, 8, 'matern52ard', 'f32', 6, False),
+        }
     if a.chain > 0 and rank == 0 and not stub:
         # chain-level cross-check: the real sampler from the framework's initial point; targets are a
         # bounded series in the reference's data range, one aux_var_model + several full SDS proposals per iteration
@@ -455,15 +560,21 @@ def main():
         line = {
             'metric': 'GP log-marginal evals/sec (= slice-sample steps/sec) at N=%d' % a.n,
             'metric_note': 'one step = ONE log-marginal evaluation (K build + Cholesky + reduction, N^3/3 flops), the unit '
-                           'SURVEY.md 8(d) defines; a full SDS proposal is 4x and a sampler iteration several proposals: '
-                           'see extra.sds_proposals_per_s / extra.chain with --full',
+                           'SURVEY.md 8(d) defines; a full SDS proposal (the reference\'s literal step) is 4x: '
+                           'extra.sds_proposals_per_s; a sampler iteration is several proposals: extra.chain with --full',
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': 1e3 * tmax / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * tmax / a.steps,
+            'ms_per_step_blocks': {'blocks': len(block_ms), 'steps_each': a.steps, 'min': min(block_ms), 'max': max(block_ms),
+                                   'median': float(np.median(block_ms)), 'all': block_ms,
+                                   'note': 'this rank, block 0 = the headline block'},
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic' if not stub else 'STUB (no GPU work; plumbing test only)',
             'config': {'workload': 'RBF kernel, N=%d, d=%d, fp64, 1 chain per GPU (BASELINE.json configs[2])' % (a.n, a.d),
                        'global_batch': world, 'parallelism': 'chain-parallel x%d (no data-path collective)' % world,
-                       'schedule': 'auto (look-ahead: one tile-DAG launch per 384-column panel beside the trailing GEMM while '
-                                   '>6144 columns remain, then one tile-DAG launch for the rest)',
+                       'schedule': 'auto (look-ahead: one tile-DAG launch per %d-column panel beside the trailing GEMM while '
+                                   '>6144 columns remain, then one tile-DAG launch for the rest)' % (512 if a.n > 8064 else 384),
+                       'shared_card': 0 if stub else int(_lib.get_option('shared_card')),
+                       'collective_backend': (dist.get_backend() if grouped else None),
                        'launch': 'recorded launch sequence (one fork/join hipGraph), replayed',
                        'enqueue': 'pipelined (back to back)' if a.pipelined else 'sync-each (result read before the next step)',
                        'g': 'GP draw chol(K+sn^2 I) z at the truth hyper-parameters (BASELINE.md 2)'},
@@ -476,7 +587,7 @@ def main():
             line['extra'] = extra
         print(json.dumps(line), flush=True)
     plan.close()
-    if world > 1:
+    if grouped:
         barrier()
         dist.destroy_process_group()
 

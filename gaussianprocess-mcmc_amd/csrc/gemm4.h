@@ -9,6 +9,10 @@
 //   wave tile  = RG row-groups (4 rows) x CG column-groups (16 columns): RG*CG independent accumulators
 //   per 8 k    = RG + CG 16-byte LDS reads for 2*RG*CG MFMAs (16 cycles each)
 // Same interface and tile decode as gemm_nt_kernel (potrf.hip).
+// Measured and removed in round 3 (DESIGN.md section 4 keeps the numbers): an XCD-aware 8x8 super-block tile order (halves
+// the panel re-reads that miss the XCD L2s, 253 vs 372 MB fetched per K = 256 launch, and is 12 % slower from the
+// super-block imbalance), folding C in after the K loop on alternate dispatch waves, start-up phase shifts of co-resident
+// workgroups, and non-temporal C accesses: all +-0 or worse.
 #pragma once
 #include "gpmc_common.h"
 
@@ -22,7 +26,7 @@ template <int WGM, int WGN, int RG, int CG, bool EPI, int KCH = 2>
 __global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
-                double diag_add, int g_desync, int xmap, int ktri, int prio_cols, unsigned* __restrict__ gflag) {
+                double diag_add, int ktri, int prio_cols, unsigned* __restrict__ gflag) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
     constexpr int BKE = 8 * KCH;                           // k elements per stage
@@ -36,37 +40,7 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     int ti, tj;
     bool is_prio = false;
     int prio_slot = 0;
-    if (xmap) {
-        // XCD-aware order (workgroups b and b+8 share an XCD and its private 4 MB L2): every XCD walks 8x8
-        // super-blocks of tiles, so its ~64 resident workgroups touch 8 A-tiles + 8 B-tiles (2 MB, each reused
-        // 8x from L2) instead of ~72 distinct operand tiles.  mt = tile rows, ntc = tile columns; slots that fall
-        // outside the (lower-triangular) tile set exit at once.
-        const int b = blockIdx.x;
-        const int xcd = b & 7, slot = b >> 3;
-        const int sb = (slot >> 6) * 8 + xcd;              // super-block id
-        const int r = (slot & 63) >> 3, cc = slot & 7;     // tile inside the super-block
-        const int SC = (ntc + 7) >> 3;                     // super-columns
-        int I, J;
-        if (tri) {
-            const int T3 = SC * (SC + 1) / 2;
-            if (sb < T3) {
-                I = (int)((sqrt(8.0 * (double)sb + 1.0) - 1.0) * 0.5);
-                while (I * (I + 1) / 2 > sb) --I;
-                while ((I + 1) * (I + 2) / 2 <= sb) ++I;
-                J = sb - I * (I + 1) / 2;
-            } else {
-                const int bb = sb - T3;
-                I = SC + bb / SC;
-                J = bb % SC;
-            }
-        } else {
-            I = sb / SC;
-            J = sb % SC;
-        }
-        ti = 8 * I + r;
-        tj = 8 * J + cc;
-        if (ti >= xmap || tj >= ntc || (tri && tj > ti)) return;   // xmap carries mt (tile rows)
-    } else if (tri && prio_cols > 0) {
+    if (tri && prio_cols > 0) {
         // Look-ahead hand-over inside the launch (potrf.hip, la_dag): the first prio_cols tile columns -- the columns of
         // the panel after next -- are processed FIRST (blocks are dispatched in index order) and every such tile
         // publishes a flag when it is in memory, so the tile-DAG launch that factors that panel starts on them while the
@@ -127,28 +101,13 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
     double acc[RG][CG];
     const int crow = row0 + wm * RG * 4 + i;        // + 4*rg
     const int ccol = col0 + wn * CG * 16 + c;       // + 16*cg
-    // Co-resident workgroups start in lock-step, so their C-tile reads (prologue) and writes (epilogue) would
-    // coincide and leave the MFMA pipe idle ~1/3 of a K=128 tile.  Every other dispatch wave of 256 workgroups
-    // therefore accumulates from zero and folds C in AFTER the K loop: one workgroup's memory phase then sits
-    // under its neighbour's MFMA phase.  (Which workgroups share a CU is a guess that only affects speed.)
-    const bool c_last = beta && ((g_desync & 0xff) == 1) && ((blockIdx.x >> 8) & 1);
-    if ((g_desync & 0xffef) >= 2) {   // experiment: delay half of the first 512 workgroups at kernel start
-        // value = 256 * bit + 2 * reps (+ 16 = streaming C, see below): blocks whose index has `bit` set (default 8,
-        // i.e. the second slot of every CU if the dispatcher deals one block per CU per pass) sleep reps x 3.4 us
-        const int bit = (g_desync >> 8) ? (g_desync >> 8) : 8;
-        const int sel = (g_desync & 1) ? (blockIdx.x & 1) : ((blockIdx.x >> bit) & 1);
-        if (sel && blockIdx.x < 512) {
-            const int reps = (g_desync & 0xe) >> 1;
-            for (int r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
-        }
-    }
-    if (beta && !c_last) {
+    if (beta) {
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg) {
                 const double* cp = &Cin[(size_t)(crow + 4 * rg) * ldcin + ccol + 16 * cg];
-                acc[rg][cg] = (g_desync & 16) ? __builtin_nontemporal_load(cp) : *cp;   // bit 4: streaming C tiles
+                acc[rg][cg] = *cp;
             }
     } else {
 #pragma unroll
@@ -227,13 +186,11 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
         for (int cg = 0; cg < CG; ++cg) {
             const int gr = crow + 4 * rg, gc = ccol + 16 * cg;
             double v = acc[rg][cg];
-            if (c_last) v += Cin[(size_t)gr * ldcin + gc];
             if (EPI) {
                 if (gr == gc) v += diag_add;
                 if (gr >= n_true || gc >= n_true) v = (gr == gc) ? 1.0 : 0.0;
             }
-            if (g_desync & 16) __builtin_nontemporal_store(v, &C[(size_t)gr * ldc + gc]);
-            else C[(size_t)gr * ldc + gc] = v;
+            C[(size_t)gr * ldc + gc] = v;
         }
     if (is_prio) {
         // publish: plain stores -> every storing wave drains -> workgroup barrier -> one lane's agent-scope release

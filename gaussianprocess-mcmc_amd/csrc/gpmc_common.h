@@ -74,6 +74,9 @@ struct Options {
                               // timeout path -- every wait that is not already satisfied aborts the launch)
     int dag_ahead = 1;        // look-ahead: the trailing GEMM hands the next-but-one panel's columns over tile by tile inside its
                               // launch (priority tile columns + flags) instead of at its end
+    int shared_card = 0;      // other processes run kernels on this card too (chains.init_distributed sets it when ranks
+                              // outnumber cards; independent processes set it themselves): the in-launch hand-over is
+                              // replaced by the event edge, so that no resident workgroup waits for an unscheduled kernel
     int dag_wprio = 0;        // wave priority (0-2) of the worker workgroups of a look-ahead panel launch (the pairs run at 3)
     int dag_hist = 1;         // look-ahead panels: 1 = the tile-DAG launch accumulates the previous panel's update itself,
                               // 0 = a GEMM launch on the panel stream does it first
@@ -82,6 +85,8 @@ struct Options {
     int use_graph = 1;        // record the plan's launch sequence once and replay it
     int replay_form = 1;      // 1: one fork/join hipGraph (6.6 ms at N=8192); 0: linear graphs cut at the cross-stream edges
                               // (7.9 ms; no exec spans two streams) -- see Sched below
+    int graveyard_max = 512;  // HIP runtimes < 7.2: fork/join execs parked instead of destroyed (sched.hip); once this many
+                              // are parked, new sequences are recorded in the SEGMENTS form
     int small_tile_m = 3072;  // trailing matrices with at most this many rows use 64x64 tiles
     int f32_nb = 256;         // outer block of the serial f32 factorisation for np_ >= 4096
     int gemm_lds_pad = -1;    // extra dynamic LDS bytes requested by the big-tile f64 GEMM under look-ahead; -1 = auto: 16000
@@ -91,8 +96,6 @@ struct Options {
     int gemm_persistent = 0;  // big-tile f64 trailing update: persistent 8-wave kernel with C-tile prefetch (gemm4p.h)
     int gemm_small_bk32 = 0;  // small-tile (64x64) f64 GEMM: 32 k per LDS stage instead of 16
     int gemm_8wave = 0;       // with a padded LDS request (one GEMM workgroup per CU) use the 8-wave 128x128 variant
-    int gemm_xcd_map = 0;     // XCD-aware 8x8 super-block tile order in the 4x4x4 GEMM (halves L2 misses, not faster)
-    int gemm_desync = 0;      // 1: alternate dispatch waves fold C in after the K loop; >= 2: phase-shift experiments
     int panel_impl = 1;       // 1: fused kernel (4 waves); 2: fused kernel with in-block look-ahead (5 waves, +-0.5 %);
                               // 0: three kernels (diag factor, strip TRSM, GEMM)
     int diag_impl = 3;        // with panel_impl 0: 0 LDS column loop, 1 single wave, 2 register-blocked VALU, 3 micro-panel + MFMA
@@ -212,16 +215,17 @@ int trmv_upper(const T* W, int n, int ldw, const T* x, const T* y0, double alpha
 // device sync put on the exec's internal branch stream when hipGraphExecDestroy frees it.  The identical libgpmc
 // binary, capture and destroy sequence is clean on runtime 7.2.26015 (with or without torch in the process), and the
 // 7.0 runtime aborts the same way from a plain C++ harness, so neither torch nor this library's capture pattern is an
-// ingredient.  drop_ops() therefore retires a fork/join exec on runtimes < 7.2 by launching it once more with EVERY
-// node disabled (nothing executes, no memory is touched) and synchronising the stream: that flushes the handler
-// thread's pending work on the internal streams, after which the destroy is safe (480 cycles in round 1 with a live
-// replay, gpmc_debug_graph_churn with the disabled one).
+// ingredient.  Round 2 flushed the exec (one launch with every node disabled + a stream sync) before destroying it,
+// which narrowed the race but left one host segmentation fault in a later capture.  Round 3: on runtimes < 7.2 a
+// fork/join exec is never destroyed -- drop_ops() parks it in a process-wide graveyard (sched.hip; count and node
+// total readable through gpmc_graveyard_stats, bounded by the option graveyard_max, beyond which sequences are
+// recorded in the SEGMENTS form).
 struct SeqOp {
     int kind;              // 0 graph launch, 1 event record, 2 stream wait
     int on_panel;          // which stream: 0 main, 1 panel
     hipGraphExec_t exec;
     hipEvent_t ev;
-    hipGraph_t graph;      // fork/join op only: the template, kept for its node handles (retirement)
+    hipGraph_t graph;      // two-stream fork/join op only: the template graph (parked with the exec on runtimes < 7.2)
 };
 struct Sched {
     enum Mode { EAGER = 0, SEGMENTS = 1, FORKJOIN = 2 };
@@ -232,6 +236,7 @@ struct Sched {
     size_t ev_next = 0;
     std::vector<SeqOp> ops;
     bool cap_main = false, cap_panel = false;
+    bool forked = false;                 // FORKJOIN: an edge has pulled the panel stream into the capture
     bool info_cleared = false;           // the caller has already cleared *info_dev on the main stream (potrf skips its memset)
 
     int init(hipStream_t main_stream);                       // creates the panel stream and a first batch of events
@@ -241,11 +246,13 @@ struct Sched {
     int begin(int mode_);                                    // SEGMENTS / FORKJOIN: start capturing
     int end();                                               // ... stop; the op list is complete
     int replay();
-    int drop_ops();                                          // destroy the recorded graphs (plain destroys)
+    int drop_ops();                                          // retire the recorded graphs (see the hazard note above)
     int destroy();                                           // + events and the panel stream
   private:
     int cut(hipStream_t s);
 };
+bool forkjoin_allowed();                        // false once the graveyard of un-destroyable execs is full
+void graveyard_stats(int* execs, size_t* nodes);
 Sched* eager_sched(hipStream_t main_stream);   // process-wide EAGER schedule for the bare gpmc_potrf_* entry points
 int trsm_rows_f64(const double* W, int np_, int ldw, double* R, int nrows, int ldr, hipStream_t s);
 int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStream_t s);

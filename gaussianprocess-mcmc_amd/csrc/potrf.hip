@@ -30,10 +30,10 @@
 // prefetch.  `make EXPERIMENTS=1` compiles them in; the default library does not carry them and their options
 // (diag_impl 1/2, panel_impl 2, gemm_persistent) are rejected by gpmc_set_option.
 #ifdef GPMC_EXPERIMENTS
-#include "diag_wave.h"
-#include "diag_rb.h"
-#include "panel_fused2.h"
-#include "gemm4p.h"
+#include "../../experiments/superseded/diag_wave.h"
+#include "../../experiments/superseded/diag_rb.h"
+#include "../../experiments/superseded/panel_fused2.h"
+#include "../../experiments/superseded/gemm4p.h"
 #endif
 
 namespace gpmc {
@@ -353,7 +353,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attr8_done = true;
                 }
                 hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)lds_pad, s, A, lda, B, ldb, Cin, ldcin,
-                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, 0, 0, ktri, 0, (unsigned*)nullptr);
+                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -367,7 +367,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attrs_done = true;
                 }
                 hipLaunchKernelGGL(ks, dim3(nblk), dim3(256), smems, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                                   alpha, beta, n_true, diag_add, 0, 0, ktri, 0, (unsigned*)nullptr);
+                                   alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -379,15 +379,8 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                 attr4_done = true;
             }
             const size_t smem4 = smem + ((BM == 128) ? (size_t)lds_pad : 0);
-            int xmap = 0, nblk4 = nblk;
-            if (g_opt.gemm_xcd_map && mt >= 16 && !gflag) {   // super-block order; grid = (#super-blocks rounded to 8) * 64
-                const int SC = (ntc + 7) / 8, SR = (mt + 7) / 8;
-                const int nsb = tri ? SC * (SC + 1) / 2 + (SR - SC) * SC : SR * SC;
-                nblk4 = ((nsb + 7) / 8 * 8) * 64;
-                xmap = mt;
-            }
-            hipLaunchKernelGGL(k4, dim3(nblk4), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                               alpha, beta, n_true, diag_add, g_opt.gemm_desync, xmap, ktri, gflag ? prio_cols : 0, gflag);
+            hipLaunchKernelGGL(k4, dim3(nblk), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
+                               alpha, beta, n_true, diag_add, ktri, gflag ? prio_cols : 0, gflag);
             GPMC_LAUNCH_CHECK();
             return 0;
         }
@@ -800,16 +793,19 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         auto la_nb_dag = [&](int rem) {
             if (g_opt.outer_nb > 0) return NB;
             (void)rem;                       // by problem size: switching 512 -> 384 below 9216 remaining columns
-            // (with the 16x16x4 accumulation NB 512 would also win below 9216 columns when a process has the card to
-            //  itself -- N = 8192: NB 384 / 192 workers 4.36 ms, NB 512 with 192 / 224 / 256 / 288 workers 4.31 / 4.31 / 4.28 /
-            //  4.29 -- but with TWO processes on one card that schedule ended in the tile-DAG spin limit in 14 of 24 runs
-            //  (0 of 4 with NB 384, the schedule the 42 earlier two-process rehearsals ran): not adopted)
-            return np_ >= 9216 ? 512 : 384;  // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
+                                             // measured worse than staying (10240: 8.31 vs 8.01, 12288: 13.43 vs 12.95)
+            // 512 from N = 8192 on (with the 16x16x4 accumulation: NB 384 / 192 workers 4.36 ms, NB 512 with 192 / 224 /
+            // 256 / 288 workers 4.31 / 4.31 / 4.28 / 4.29).  Round 2 held this back because two PROCESSES on one card ran
+            // that schedule into the spin limit (14 of 24 runs): a gated panel launch of 8 + 256 workgroups spins on flags
+            // of a GEMM that may not be resident yet, and two of them (528 workgroups) fill all 512 CU slots so that
+            // neither GEMM can place a block.  That wait is now structurally absent when the card is shared (option
+            // shared_card, below: stream-ordered hand-over), so the outer block no longer has to guard against it.
+            return np_ >= 8192 ? 512 : 384;
         };
         auto panel_workers = [&](int nb, int rem) {
             if (g_opt.dag_workers > 0) return g_opt.dag_workers;
             (void)rem;   // by problem size too: more workers as the remaining columns shrink loses (12288: 13.54 vs 12.95)
-            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : 224);
+            if (nb >= 512) return np_ >= 14336 ? 128 : (np_ >= 11264 ? 160 : (np_ >= 9216 ? 224 : 256));
             return nb / 2;
         };
         hipEvent_t pe, ge = nullptr;
@@ -822,8 +818,13 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // instead of on G_k's end: the panel chain runs up to a step ahead of the GEMM chain, which then runs back to
         // back.  Words of G_k's flags: (tile columns of panel k+2) x (tile rows of its region), 0 when not used.
         auto next_nb = [&](int kk) { return (np_ - kk < la_nb_dag(np_ - kk)) ? np_ - kk : la_nb_dag(np_ - kk); };
+        // Not when other processes use the card too (shared_card): the gated launch's workgroups hold CU slots while they
+        // wait for a producer that may not have been dispatched, and with another process's launches competing for the
+        // same slots that wait can outlast the spin limit.  The hand-over is then the event edge ge (stream order): no
+        // workgroup of a panel launch ever waits for another kernel.
         auto handover_words = [&](int k1, int k2) -> size_t {
-            if (sizeof(T) != 8 || !g_opt.dag_ahead || !g_opt.dag_hist || g_opt.gemm_impl != 1 || k2 >= np_ || hand_over(k2))
+            if (sizeof(T) != 8 || !g_opt.dag_ahead || g_opt.shared_card || !g_opt.dag_hist || g_opt.gemm_impl != 1 ||
+                k2 >= np_ || hand_over(k2))
                 return 0;
             const int rows = mp_at(k1) - k2;
             if (rows <= g_opt.small_tile_m || rows % 128 || (np_ - k2) % 128) return 0;

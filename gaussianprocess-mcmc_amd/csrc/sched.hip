@@ -1,5 +1,7 @@
 // sched.hip -- the launch schedule object (gpmc_common.h `Sched`): two streams, cross-stream edges, and the
 // segmented record / replay form the plan uses instead of one fork/join hipGraph.
+#include <mutex>
+
 #include "gpmc_common.h"
 
 namespace gpmc {
@@ -75,6 +77,7 @@ int Sched::edge_wait(hipStream_t s, hipEvent_t e) {
         ops.push_back(SeqOp{2, s == panel ? 1 : 0, nullptr, e, nullptr});
         return 0;
     }
+    if (mode == FORKJOIN && s == panel) forked = true;      // the capture now spans two streams
     GPMC_HIP(hipStreamWaitEvent(s, e, 0));
     return 0;
 }
@@ -83,6 +86,7 @@ int Sched::begin(int mode_) {
     if (!ops.empty()) return fail(-1, "Sched::begin: a recorded sequence already exists");
     mode = mode_;
     ev_next = 0;
+    forked = false;
     if (mode == EAGER) return 0;
     GPMC_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
     cap_main = true;
@@ -91,7 +95,9 @@ int Sched::begin(int mode_) {
 
 int Sched::end() {
     if (mode == EAGER) return 0;
-    const bool forkjoin = (mode == FORKJOIN);
+    // only an exec whose graph really spans two streams gets an internal branch stream from the runtime: a FORKJOIN
+    // recording of a one-stream schedule (every problem the tile-DAG kernel takes whole) is a linear graph
+    const bool forkjoin = (mode == FORKJOIN) && forked;
     int rc = 0;
 
     // close what is still open; a failed launch sequence must not leave a stream in capture mode
@@ -132,29 +138,62 @@ int Sched::replay() {
     return 0;
 }
 
-// HIP runtimes before 7.2 need a fork/join exec flushed before it is destroyed (gpmc_common.h, Sched)
-static bool forkjoin_needs_flush() {
-    static int need = -1;
-    if (need < 0) {
+// HIP runtimes before 7.2: destroying a fork/join exec is a use-after-free inside the runtime (gpmc_common.h, Sched),
+// and "flush, then destroy" (round 2) only narrowed the window -- one host segmentation fault in a later capture was
+// the same heap corruption.  On those runtimes a retired fork/join exec is therefore NEVER destroyed while the process
+// lives: it is parked, with its template graph, in a process-wide graveyard (a leaked object: no destructor runs at
+// unload either, so nothing of the runtime is touched after main()).  The graveyard is bounded: once it holds
+// g_opt.graveyard_max execs (default 512) forkjoin_allowed() turns false and new sequences are recorded in the SEGMENTS form, whose linear
+// single-stream execs have no internal branch stream and are destroyed normally.
+static bool forkjoin_destroy_unsafe() {
+    static int unsafe = -1;
+    if (unsafe < 0) {
         int v = 0;
-        need = (hipRuntimeGetVersion(&v) != hipSuccess || v < 70200000) ? 1 : 0;
+        unsafe = (hipRuntimeGetVersion(&v) != hipSuccess || v < 70200000) ? 1 : 0;
     }
-    return need == 1;
+    return unsafe == 1;
+}
+
+namespace {
+
+struct Graveyard {
+    std::mutex mu;
+    std::vector<hipGraphExec_t> execs;
+    std::vector<hipGraph_t> graphs;
+    size_t nodes = 0;
+};
+Graveyard& graveyard() {
+    static Graveyard* g = new Graveyard();      // leaked on purpose
+    return *g;
+}
+}  // namespace
+
+void graveyard_stats(int* execs, size_t* nodes) {
+    Graveyard& g = graveyard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (execs) *execs = (int)g.execs.size();
+    if (nodes) *nodes = g.nodes;
+}
+
+bool forkjoin_allowed() {
+    if (!forkjoin_destroy_unsafe()) return true;
+    Graveyard& g = graveyard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    return (int)g.execs.size() < g_opt.graveyard_max;
 }
 
 int Sched::drop_ops() {
     int rc = 0;
     for (SeqOp& o : ops) {
         if (o.kind != 0 || !o.exec) continue;
-        if (o.graph && forkjoin_needs_flush()) {
-            // one launch with every node disabled: nothing runs, nothing is read or written
+        if (o.graph && forkjoin_destroy_unsafe()) {
+            Graveyard& g = graveyard();
+            std::lock_guard<std::mutex> lk(g.mu);
             size_t n = 0;
-            bool ok = (hipGraphGetNodes(o.graph, nullptr, &n) == hipSuccess);
-            std::vector<hipGraphNode_t> nodes(n);
-            ok = ok && (n == 0 || hipGraphGetNodes(o.graph, nodes.data(), &n) == hipSuccess);
-            for (size_t i = 0; ok && i < n; ++i) ok = (hipGraphNodeSetEnabled(o.exec, nodes[i], 0) == hipSuccess);
-            if (ok && hipGraphLaunch(o.exec, main) == hipSuccess) (void)hipStreamSynchronize(main);
-            else if (!rc) rc = fail(-1, "Sched::drop_ops: could not flush a fork/join exec before destroying it");
+            if (hipGraphGetNodes(o.graph, nullptr, &n) == hipSuccess) g.nodes += n;
+            g.execs.push_back(o.exec);
+            g.graphs.push_back(o.graph);
+            continue;
         }
         hipError_t e = hipGraphExecDestroy(o.exec);
         if (e != hipSuccess && !rc) rc = fail((int)e, "hipGraphExecDestroy: %s", hipGetErrorString(e));

@@ -26,8 +26,9 @@
 //   its T + 1 workgroups in (512 slots; T <= 112), that one finishes and frees its slots.  (Roles by block index, the
 //   first version, tied each pair to the XCD its index is dealt to; two processes on one card then deadlocked now and
 //   then, each holding the XCDs the other's pairs were queued for.)  Every spin is bounded all the same: a workgroup
-//   that gives up raises the abort word, every other spin sees it within 256 polls, all leave and *info becomes
-//   GPMC_TAIL_TIMEOUT -- the grid always drains.
+//   that gives up writes WHICH wait ran out into *info (tail_timeout_code: GEMM hand-over flag / operand tile /
+//   diagonal factor + the tile column), raises the abort word, every other spin sees it within 256 polls and all
+//   leave -- the grid always drains.
 // * Publishing = writing the tile to its place in W with write-through (sc1) stores, every storing wave draining its
 //   stores, a workgroup barrier, then ONE lane's agent-scope flag store; consumers poll the flag (one lane, relaxed
 //   sc1 loads, s_sleep between polls), pass a workgroup barrier and read the tile with sc1 loads -- the "8-byte agent
@@ -56,7 +57,16 @@ constexpr int TAIL_CUS = 1024;
 __host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS + TAIL_MAXT; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // default number of polls before giving up (~1 s)
-constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting
+constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting and no cause was recorded
+// *info of the workgroup whose wait actually ran out: -(1000000 + 10000 cause + global tile column it waited for)
+//   cause 1: a hand-over flag of the trailing GEMM running beside the launch (gemm4.h, prio_cols)
+//   cause 2: an operand tile of an earlier column (flag[col][row] of a worker or pair of this launch)
+//   cause 3: the diagonal factor L_{col,col} (the pair of that column)
+constexpr int GPMC_TAIL_TIMEOUT_BASE = -1000000;
+constexpr int TAIL_WAIT_GEMM = 1, TAIL_WAIT_TILE = 2, TAIL_WAIT_FACTOR = 3;
+__host__ __device__ inline int tail_timeout_code(int cause, int gcol) {
+    return GPMC_TAIL_TIMEOUT_BASE - 10000 * cause - (gcol < 0 ? 0 : (gcol > 9999 ? 9999 : gcol));
+}
 
 struct TailShared {
     double Ld[64][MP_LD];     // A operand of an update; the diagonal factor (Lout) during FACTOR / TRSM
@@ -166,8 +176,10 @@ __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "mem
 // all 256 threads; true once *f1 != 0 and *f2 != 0.  One lane polls; the result reaches the others through LDS.
 // acquire = true: the bytes behind the flags were written with PLAIN stores and released (the GEMM's hand-over tiles):
 // the polling lane follows its poll with an agent-scope acquire (drops this CU's stale L1 lines) before the barrier
+// why = tail_timeout_code(cause, column): written to *info by the lane whose own budget ran out, BEFORE it raises the abort
+// word, so that the code that reaches the host names the wait that expired, not one that merely saw the abort
 __device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsigned* abortw, TailShared& sh, int tid,
-                                  unsigned spin_limit, bool acquire = false) {
+                                  unsigned spin_limit, int* info, int why, bool acquire = false) {
     if (tid == 0) {
         int ok = 1;
         for (unsigned spins = 0;; ++spins) {
@@ -175,6 +187,7 @@ __device__ inline bool tail_wait2(const unsigned* f1, const unsigned* f2, unsign
             if (a != 0u && b != 0u) break;
             if ((spins & 255u) == 255u && tail_ld32(abortw) != 0u) { ok = 0; break; }
             if (spins >= spin_limit) {
+                atomicCAS(info, 0, why);
                 __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -315,7 +328,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
         const int ci = pair ? tl : ti, cl0 = pair ? (tl >= 1 ? tl - 1 : tl) : tl;
         if ((ci >> 1) < gmt) {      // (rows beyond the update's range are untouched by it)
             alive = tail_wait2(gflag + (cl0 >> 1) * gmt + (ci >> 1), gflag + (tl >> 1) * gmt + (ci >> 1), abortw, sh, tid,
-                               spin_limit, true);
+                               spin_limit, info, tail_timeout_code(TAIL_WAIT_GEMM, gb + tl), true);
             if (!alive) break;
         }
     }
@@ -485,7 +498,8 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
         if (nready > 0) {
             ready_upto = col + nready;
         } else {
-            alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit);
+            alive = tail_wait2(flag(col, xl), flag(col, xi), abortw, sh, tid, spin_limit, info,
+                               tail_timeout_code(TAIL_WAIT_TILE, gb + col));
             ready_upto = col + 1;
         }
     };
@@ -529,7 +543,8 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     TAIL_STAMP(1);
     if (pair && !warm && busy != nullptr && tid == 0) __hip_atomic_fetch_add(busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (alive && xl >= 0 && !warm) {
-        alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid, spin_limit);
+        alive = tail_wait2(flag(xl, xl), flag(xl, xl), abortw, sh, tid, spin_limit, info,
+                           tail_timeout_code(TAIL_WAIT_FACTOR, gb + xl));
         TAIL_STAMP(2);
         if (alive) {
             tail_tile_in(Lout, tile(xl, xl), ld, tid);

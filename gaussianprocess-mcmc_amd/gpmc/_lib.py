@@ -77,6 +77,12 @@ def _sig(lib):
         'gpmc_plan_workspace': ([P, ctypes.POINTER(c_void_p), ctypes.POINTER(I), ctypes.POINTER(I),
                                  ctypes.POINTER(I)], I),
         'gpmc_plan_destroy': ([P], I),
+        'gpmc_graveyard_stats': ([ctypes.POINTER(I), ctypes.POINTER(c_size_t)], I),
+        'gpmc_debug_panel_stamps': ([P, I, I, I, I, P, P, I, P, P], I),
+        'gpmc_debug_tail_stamps': ([P], I),
+        'gpmc_debug_graph_churn': ([P, I, I, I], I),
+        'gpmc_debug_plan_record_info': ([P, ctypes.POINTER(c_double)], I),
+        'gpmc_debug_plan_ops': ([P, ctypes.POINTER(I), ctypes.POINTER(I)], I),
         'gpmc_trsm_rows_f64': ([P, I, I, P, I, I, P], I),
         'gpmc_revt_lower_f64': ([P, I, I, P, I, P], I),
         'gpmc_gemm_nt_f64': ([P, I, P, I, P, I, I, I, I, P], I),
@@ -115,17 +121,43 @@ def check(rc, what=''):
 
 
 TAIL_TIMEOUT = -1001     # *info when the tile-DAG kernel (csrc/tail.h) gave up waiting: an error, not "not positive definite"
+TAIL_TIMEOUT_BASE = -1000000     # ... with the wait that ran out: -(1000000 + 10000 cause + tile column), csrc/tail.h
+TAIL_WAIT_CAUSES = {1: "a hand-over flag of the trailing GEMM running beside the launch",
+                    2: "an operand tile of an earlier column",
+                    3: "the diagonal factor of a column"}
+
+
+def decode_timeout(info):
+    """(cause, tile column) of a tile-DAG timeout code, or None if ``info`` is not one"""
+    info = int(info)
+    if info == TAIL_TIMEOUT:
+        return 0, -1
+    if info <= TAIL_TIMEOUT_BASE:
+        v = -info - 1000000
+        return v // 10000, v % 10000
+    return None
 
 
 def check_info(info):
-    """pass a factorisation's LAPACK-style info through; raise if it is the tile-DAG kernel's timeout code (its
-    bounded spins ran out: the GPU was held by other work for about a second, or blocks were not dispatched in
-    index order)"""
+    """pass a factorisation's LAPACK-style info through; raise if it is a tile-DAG timeout code (the kernel's bounded
+    spins ran out: the GPU was held by other work for about a second, or a producer kernel was never dispatched).  The
+    message names the wait that expired."""
     info = int(info)
-    if info == TAIL_TIMEOUT:
-        raise GpmcError('tile-DAG factorisation kernel timed out waiting for another workgroup (info=%d); '
-                        'set_option("tail_m", 0) selects the launch-chain schedule' % info)
+    t = decode_timeout(info)
+    if t is not None:
+        cause, col = t
+        what = TAIL_WAIT_CAUSES.get(cause, 'another workgroup')
+        raise GpmcError('tile-DAG factorisation kernel timed out waiting for %s%s (info=%d); if other processes share '
+                        'this card call set_option("shared_card", 1); set_option("tail_m", 0) selects the launch-chain '
+                        'schedule' % (what, (' (tile column %d)' % col) if col >= 0 else '', info))
     return info
+
+
+def graveyard_stats():
+    """(execs, nodes) parked instead of destroyed on HIP runtimes < 7.2 (include/gpmc.h, gpmc_graveyard_stats)"""
+    e, n = c_int(), c_size_t()
+    check(lib().gpmc_graveyard_stats(ctypes.byref(e), ctypes.byref(n)), 'gpmc_graveyard_stats')
+    return int(e.value), int(n.value)
 
 
 def set_option(name, value):

@@ -17,17 +17,22 @@ _ES = {torch.float64: 8, torch.float32: 4}
 
 class LogMarginalPlan(object):
     """One (kernel, X, g) problem bound to device memory it owns; ``plan(hyp)`` / ``eval_async`` + ``result`` evaluate
-    the log-marginal at fresh hyper-parameters.  The first evaluation launches eagerly, the second records the launch
-    sequence (and validates it against the eager time, csrc/plan.hip ``record_sequence``), later ones replay it."""
+    the log-marginal at fresh hyper-parameters.  The first two evaluations launch eagerly (the second one is timed), the
+    third records the launch sequence (and validates it against that time, csrc/plan.hip ``record_sequence``), later
+    ones replay it."""
 
     def __init__(self, X, g, kernel='rbf', dtype=torch.float64, settle=None):
         """``settle`` (None = auto: on for two-stream schedules, i.e. more than tail_m columns): the fork/join exec of the
         recorded launch sequence has its branch mapped onto a hardware queue by the runtime; when that is the queue of
         the plan's own stream -- every 4th stream of torch's pool -- the two chains partly serialise (+12 % at
         N = 8192; re-instantiating does not move it, another stream does).  Which pool stream a plan
-        gets depends on what else the process created before (RCCL, other plans), so for those sizes the constructor
-        warms the plan up on two consecutive pool streams, times three replays on each and keeps the faster
-        (~60 ms once; the plan is then recorded and validated)."""
+        gets depends on what else the process created before (RCCL, other plans).  The C side validates every recording
+        against the plan's own eager evaluation (csrc/plan.hip ``record_sequence``); the constructor warms the plan up
+        (three evaluations: eager, eager timed, recorded) and looks at that verdict: a fork/join recording accepted at the
+        first attempt stays -- ONE exec per plan, nothing thrown away.  Only if the recording had to be repeated or fell
+        back to the segmented form is the plan created once more on the next pool stream (another hardware queue) and
+        the faster of the two kept; the loser's exec is retired through ``Sched::drop_ops`` (parked, not destroyed, on
+        HIP runtimes < 7.2)."""
         ops.require_gpu()
         self.kernel = kernel
         self.dtype = dtype
@@ -54,15 +59,18 @@ class LogMarginalPlan(object):
         self.settled = None
         if settle:
             t_a = self._warm()
-            keep = (self._stream, self._h)
-            self._create()                                   # the next stream of the pool: another hardware queue
-            t_b = self._warm()
-            self.settled = (t_a, t_b)
-            if t_b < 0.98 * t_a:
-                L.gpmc_plan_destroy(keep[1])
-            else:
-                L.gpmc_plan_destroy(self._h)
-                self._stream, self._h = keep
+            _, _, attempts, form = self.record_info()
+            self.settled = (t_a, None)
+            if not (form == 2 and attempts == 1):
+                keep = (self._stream, self._h)
+                self._create()                               # the next stream of the pool: another hardware queue
+                t_b = self._warm()
+                self.settled = (t_a, t_b)
+                if t_b < 0.98 * t_a:
+                    L.gpmc_plan_destroy(keep[1])
+                else:
+                    L.gpmc_plan_destroy(self._h)
+                    self._stream, self._h = keep
 
     def _create(self):
         """a plan handle on a pool stream of its own (the legacy NULL stream torch starts on cannot be captured)"""
@@ -77,15 +85,15 @@ class LogMarginalPlan(object):
                    'gpmc_plan_set_data')
 
     def _warm(self, reps=3):
-        """two evaluations at neutral parameters [sf2, Sii, ell..] = 1 (K + I is positive definite, the time does not
-        depend on the values) -- the eager one and the one that records the launch sequence -- then the wall time per
-        evaluation of ``reps`` replays, in ms"""
+        """three evaluations at neutral parameters [sf2, Sii, ell..] = 1 (K + I is positive definite, the time does not
+        depend on the values) -- two eager ones (the second is the C side's yardstick) and the one that records the
+        launch sequence -- then the wall time per evaluation of ``reps`` replays, in ms"""
         import time
         L = _lib.lib()
         kp = np.ones(2 + (1 if self.kernel == 'rbf' else self.d), dtype=np.float64)
         ptr = kp.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         out = (ctypes.c_double * 4)()
-        for _ in range(2):
+        for _ in range(3):
             _lib.check(L.gpmc_plan_logml_async(self._h, ptr, kp.shape[0], 0), 'gpmc_plan_logml_async')
             _lib.check(L.gpmc_plan_result(self._h, 0, out), 'gpmc_plan_result')
         t0 = time.perf_counter()
@@ -98,7 +106,6 @@ class LogMarginalPlan(object):
     def record_info(self):
         """(eager ms, first replay ms, recording attempts, form: 2 fork/join / 1 linear segments / -1 none yet)"""
         L = _lib.lib()
-        L.gpmc_debug_plan_record_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         out = (ctypes.c_double * 4)()
         _lib.check(L.gpmc_debug_plan_record_info(self._h, out), 'gpmc_debug_plan_record_info')
         return float(out[0]), float(out[1]), int(out[2]), int(out[3])

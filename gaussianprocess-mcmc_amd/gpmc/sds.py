@@ -214,7 +214,8 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     m = g - P (L^-1 g).  Both factorisations go through ``jitter_schedule`` as the reference's go through jitchol
     (sliceSample.py:196,205).  As in the reference the K+S that is RETURNED is the unjittered one (:207); a jitter j
     that chol(K+S) needed acts as S' = S + j I in R and m = R S^-1 g (algebraically the reference's
-    K - K (K+S+jI)^-1 K)."""
+    K - K (K+S+jI)^-1 K); the riding right-hand side is then D g with D = (S + jI) S^-1, which makes m exact for a
+    non-constant diagonal S too (a scalar rescaling of m afterwards is only right for S = s I)."""
     Kd = ops.to_dev(K)
     n = Kd.shape[0]
     dev, dt = Kd.device, Kd.dtype
@@ -236,9 +237,11 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     scratch = ops.potrf_scratch(np_, dev)
 
     def factor_A(jitter):
+        # the riding row holds g' = D g, D = (S + jitter I) S^-1 (= g without jitter), so that g' - P (L^-1 g') below is
+        # R S^-1 g for ANY diagonal S: R S^-1 g = (S' - S' A'^-1 S') S^-1 g = g' - S' A'^-1 g' with S' = S + jitter I
         ops.pack_lower(KS, WA, np_, jitter)
         WA[np_:].zero_()
-        WA[np_, :n].copy_(g)
+        WA[np_, :n].copy_(g * ((Sii + jitter) / Sii) if jitter else g)
         torch.diagonal(rows)[:n].copy_(Sii + jitter)
         if np_ > n:
             torch.diagonal(rows)[n:].fill_(1.0)
@@ -249,9 +252,8 @@ def aux_var_model(f, K, sn, g=None, kernel_ws=None):
     L = ops.unpack_lower(WA, np_, n)
     SA = Sii + jA
     m = torch.empty(n, dtype=dt, device=dev)
-    ops.trmv_upper(rows, n, WA[np_], g, -1.0, m)             # g - P alpha
-    if jA:
-        m.mul_(SA / Sii)                                     # R S^-1 g with the unjittered S (sliceSample.py:204)
+    gp = g * (SA / Sii) if jA else g                         # D g, see factor_A
+    ops.trmv_upper(rows, n, WA[np_], gp, -1.0, m)            # g' - P (L^-1 g') = R S^-1 g with the unjittered S (sliceSample.py:204)
     WR = torch.zeros((np_ + ops.PAD, np_), dtype=dt, device=dev)
     R0 = torch.empty((np_, np_), dtype=dt, device=dev)
     ops.syrk_tri(rows, R0, n, np_, 0.0)                      # -P P^T (identity on the padding)

@@ -179,9 +179,15 @@ int gpmc_gemm_nt_f64(const double* A, int lda, const double* B, int ldb, double*
 /* ---- fused plan: one log-marginal evaluation per call -------------------------------------------
  * The metric's unit (a1 + a2 + a3 + a11): for hyper-parameters hyp (host, linear
  * scale: ell[1 or d], sf, sn) build K + S into the plan's workspace, factor it with g riding as an
- * extra row, reduce.  The launch sequence is recorded once per plan as linear hipGraphs cut at the cross-stream edges
- * of the look-ahead (the plan owns its second stream and events) and replayed.
+ * extra row, reduce.  The launch sequence (~15 launches at N = 8192, two streams; the plan owns its second stream and
+ * events) is recorded on the plan's third evaluation -- the first two launch eagerly, the second one timed as the
+ * yardstick -- as ONE fork/join hipGraph and replayed; a recording that replays more than 4 % slower than the eager
+ * yardstick (the runtime mapped its branch onto the main stream's hardware queue) is retired and recorded once more,
+ * then the fallback form (linear hipGraphs cut at the cross-stream edges, replayed with eager event edges) is used.
  * All device memory is the caller's: `workspace` of gpmc_plan_workspace_bytes(n, d, elem_size).
+ * The library assumes ONE device and ONE host thread per process (the reference is a single-threaded script,
+ * framework.py:68; the deployment is one process per GPU): options, the bare entry points' eager look-ahead stream
+ * and the per-kernel attribute flags are process-wide and unsynchronised.
  */
 typedef struct gpmc_plan gpmc_plan;
 size_t gpmc_plan_workspace_bytes(int n, int d, int elem_size);
@@ -205,6 +211,12 @@ int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
 /* synchronises the plan's streams and releases the plan (its look-ahead stream, events and recorded launch graphs).
  * The stream passed to gpmc_plan_create must still be valid; the workspace is not touched. */
 int gpmc_plan_destroy(gpmc_plan* p);
+/* HIP runtimes before 7.2 (the one the torch wheel bundles is 7.0.51831) corrupt the heap when a two-stream graph exec
+ * is destroyed (a use-after-free inside the runtime, profiles/r02_graph_abort_isolation.txt): on those runtimes retired
+ * execs are parked for the life of the process instead.  execs / nodes = how many are parked and how many graph nodes
+ * they hold (either pointer may be NULL).  Option "graveyard_max" (default 512) bounds the count: beyond it new plans
+ * record the fallback form, whose single-stream execs are destroyed normally. */
+int gpmc_graveyard_stats(int* execs, size_t* nodes);
 
 /* instrumentation of the two kernels of the factorisation: between begin and read every launch of the trailing SYRK
  * update and of the tile-DAG kernel (look-ahead panels, tail) is bracketed by HIP events on the stream it goes to;
@@ -222,11 +234,25 @@ int gpmc_profile_read(double* out6);
  * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "tail_park", "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
  * "tail_acc16" (1: off-diagonal accumulation on v_mfma_f64_16x16x4; 0: the 4x4x4 form, same bits), "tail_prefetch_t" (tail /
  * whole launches of at least this many tile columns prefetch the next column's operands; 0 = never), "dag_prefetch",
- * "replay_form"; alternative kernels
- * "gemm_impl", "gemm_persistent", "gemm_small_bk32", "gemm_8wave", "gemm_xcd_map", "gemm_desync", "panel_impl",
+ * "replay_form", "graveyard_max", "shared_card" (1: other processes use this card too -- see INTEGRATION.md section 4); alternative kernels
+ * "gemm_impl", "gemm_persistent", "gemm_small_bk32", "gemm_8wave", "panel_impl",
  * "diag_impl".  Unknown names return an error. */
 int gpmc_set_option(const char* name, int value);
 int gpmc_get_option(const char* name);
+
+/* ---- diagnostics (used by tests/ and scripts/, not by the product path) ------------------------------------------
+ * panel_stamps / tail_stamps: s_memtime phase stamps of the fused panel kernel / of the tile-DAG kernel's pair
+ *   workgroups (eager launches write 16 stamps per tile column into dbg_dev until called again with NULL);
+ * graph_churn: per iteration record the plan's sequence (form 1 fork/join, 0 segments), replay, sync, optionally
+ *   hipDeviceSynchronize, retire it -- the pattern that aborted in round 1;
+ * plan_record_info: out4 = {eager yardstick ms, first replay ms, recording attempts, form (2 fork/join, 1 segments)};
+ * plan_ops: ops / graph launches of the recorded sequence. */
+int gpmc_debug_panel_stamps(double* W, int ld, int mp, int k0, int c0, int* info_dev, void* scratch, int np_,
+                            unsigned long long* dbg_dev, gpmc_stream_t stream);
+int gpmc_debug_tail_stamps(unsigned long long* dbg_dev);
+int gpmc_debug_graph_churn(gpmc_plan* p, int form, int device_sync, int iters);
+int gpmc_debug_plan_record_info(gpmc_plan* p, double* out4);
+int gpmc_debug_plan_ops(gpmc_plan* p, int* n_ops, int* n_graphs);
 
 #ifdef __cplusplus
 }

@@ -312,3 +312,21 @@ def test_bench_under_a_launcher_keeps_working():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_timeout_codes_and_shared_card_detection(monkeypatch):
+    """host logic of round 3: the tile-DAG kernel's per-cause timeout codes (csrc/tail.h tail_timeout_code) decode to
+    (cause, tile column) and raise GpmcError naming the wait; ordinary LAPACK info passes through; shared-card detection
+    reads LOCAL_WORLD_SIZE only and never guesses from WORLD_SIZE."""
+    from gpmc import _lib, chains
+    assert _lib.decode_timeout(0) is None and _lib.decode_timeout(17) is None and _lib.decode_timeout(-7) is None
+    assert _lib.decode_timeout(-1001) == (0, -1)
+    assert _lib.decode_timeout(-1010042) == (1, 42) and _lib.decode_timeout(-1030000) == (3, 0)
+    assert _lib.check_info(0) == 0 and _lib.check_info(4097.0) == 4097
+    for code, word in ((-1010042, 'GEMM'), (-1020007, 'operand tile'), (-1030127, 'diagonal factor'), (-1001, 'another workgroup')):
+        with pytest.raises(_lib.GpmcError, match='timed out') as ei:
+            _lib.check_info(code)
+        assert word in str(ei.value) and 'shared_card' in str(ei.value)
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    monkeypatch.setenv('WORLD_SIZE', '16')
+    assert chains.ranks_share_a_card() is False          # multi-node launch without LOCAL_WORLD_SIZE: nothing is guessed

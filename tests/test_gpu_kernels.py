@@ -282,7 +282,7 @@ def test_panel_and_gemm_variants_agree(gp):
 def test_large_size_schedule_options_agree(gp):
     """Options of round 1's launch-chain schedule (tail_m = 0, la_dag = 0: what f32 storage still runs), which only take
     effect with big tiles / look-ahead (N = 4096, look-ahead forced from the start):
-    schedule-only ones (depth-2 look-ahead, enqueue order, panel priority, LDS pad = CU sharing, XCD tile order) must
+    schedule-only ones (depth-2 look-ahead, enqueue order, panel priority, LDS pad = CU sharing) must
     reproduce the default's bits; alternative GEMM kernels (persistent, 8-wave, BK=32 small tiles) the same value to
     rounding.  All within 1e-10 of SciPy."""
     n = 4096
@@ -292,10 +292,10 @@ def test_large_size_schedule_options_agree(gp):
     base = {'lookahead': 1, 'outer_nb': 256, 'la_min_m': 1024, 'small_tile_m': 1024, 'tail_m': 0, 'tail_whole_m': 0,
             'la_dag': 0}
     reset = {'lookahead': -1, 'outer_nb': 0, 'la_min_m': 2048, 'small_tile_m': 3072, 'la_depth': 1, 'la_order': 0,
-             'panel_prio': 1, 'gemm_lds_pad': -1, 'gemm_xcd_map': 0, 'gemm_8wave': 0,
+             'panel_prio': 1, 'gemm_lds_pad': -1, 'gemm_8wave': 0,
              'gemm_small_bk32': 0, 'tail_m': 6144, 'tail_whole_m': 7168, 'la_dag': 1, 'la_min_np': 4096}
     variants = [('default', {}), ('depth2', {'la_depth': 2}), ('order1', {'la_order': 1}), ('noprio', {'panel_prio': 0}),
-                ('share_cu', {'gemm_lds_pad': 9216, 'panel_prio': 1}), ('xcd_map', {'gemm_xcd_map': 1}),
+                ('share_cu', {'gemm_lds_pad': 9216, 'panel_prio': 1}),
                 ('eight_wave', {'gemm_8wave': 1}), ('bk32', {'gemm_small_bk32': 1}),
                 ('dag look-ahead + tile-DAG tail', {'tail_m': 2048, 'tail_whole_m': 0, 'la_dag': 1, 'la_min_np': 1024,
                                                     'outer_nb': 256})]
@@ -317,7 +317,7 @@ def test_large_size_schedule_options_agree(gp):
     for name, v in vals.items():
         assert v[0] == v[1], name
         assert abs(v[0] - ref) <= 1e-10 * abs(ref), (name, v[0], ref)
-    for name in ('depth2', 'order1', 'noprio', 'share_cu', 'xcd_map'):
+    for name in ('depth2', 'order1', 'noprio', 'share_cu'):
         assert vals[name][0] == vals['default'][0], name
 
 
@@ -472,12 +472,13 @@ def test_plan_input_dimension_limits(gp):
 
 # ---------------------------------------------------------------------------------- plan lifecycle (round 2)
 def _churn(gp, plan, form, devsync, iters):
-    import ctypes
     from gpmc import _lib
-    L = _lib.lib()
-    L.gpmc_debug_graph_churn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    L.gpmc_debug_graph_churn.restype = ctypes.c_int
-    _lib.check(L.gpmc_debug_graph_churn(plan._h, form, devsync, iters), 'gpmc_debug_graph_churn')
+    _lib.check(_lib.lib().gpmc_debug_graph_churn(plan._h, form, devsync, iters), 'gpmc_debug_graph_churn')
+
+
+def _runtime_destroys_are_unsafe():
+    """HIP runtimes before 7.2 (torch bundles 7.0.51831, and libgpmc.so resolves to the runtime torch loaded)"""
+    return tuple(int(v) for v in torch.version.hip.split('.')[:2]) < (7, 2)
 
 
 @pytest.mark.parametrize('form', [1, 0])
@@ -485,10 +486,11 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
     """Round 1's abort (VERDICT weak #12): a replayed launch graph destroyed after a device-wide sync, on the look-ahead
     schedule (n = 7300 -> two streams).  Root cause (profiles/r02_graph_abort_isolation.txt): a use-after-free inside
     HIP runtime 7.0.51831 -- the one torch bundles, i.e. the one this test runs on -- when a FORK/JOIN exec is destroyed
-    after hipDeviceSynchronize.  form 1 = the default fork/join replay, retired through a launch with every node
-    disabled; form 0 = linear graphs cut at the cross-stream edges, plain destroys.  Both must survive record / replay /
-    hipDeviceSynchronize / destroy cycles, leave the workspace alone while retiring, and the plan usable and
-    bit-identical afterwards."""
+    after hipDeviceSynchronize.  form 1 = the default fork/join replay: on such runtimes its execs are never destroyed
+    but parked in the process-wide graveyard (csrc/sched.hip), whose count must grow by exactly the number of execs
+    retired here; form 0 = linear graphs cut at the cross-stream edges, plain destroys, graveyard untouched.  Both must
+    survive record / replay / hipDeviceSynchronize / retire cycles, leave the workspace alone while retiring, and the
+    plan usable and bit-identical afterwards."""
     import ctypes
     from gpmc import _lib
     gpmc = gp['gpmc']
@@ -500,15 +502,21 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
         plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
         before = [plan(hyp) for _ in range(2)]
         L = _lib.lib()
-        L.gpmc_debug_plan_ops.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         nops, ngr = ctypes.c_int(), ctypes.c_int()
         _lib.check(L.gpmc_debug_plan_ops(plan._h, ctypes.byref(nops), ctypes.byref(ngr)), 'gpmc_debug_plan_ops')
         if form == 0:
             assert ngr.value >= 3 and nops.value > ngr.value    # really cut at cross-stream edges: graphs + event ops
         else:
             assert ngr.value == 1 and nops.value == 1
+        parked0, nodes0 = _lib.graveyard_stats()
         _churn(gp, plan, form, 1, 8)
         torch.cuda.synchronize()
+        parked1, nodes1 = _lib.graveyard_stats()
+        if form == 1 and _runtime_destroys_are_unsafe():
+            assert parked1 - parked0 == 9                        # the plan's own recording + 8 churned ones
+            assert nodes1 - nodes0 >= 9 * 10                     # each holds the ~15 launches of an evaluation
+        else:
+            assert (parked1, nodes1) == (parked0, nodes0)
         after = plan(hyp)                                        # re-records after the churn dropped the sequence
         assert after == before[0] == before[1]
         ref = sds_ref.gp_log_marginal(x, g, hyp)
@@ -567,9 +575,16 @@ def test_tile_dag_bounded_spins_drain_the_grid_and_surface_as_an_error(gp):
         gpmc.set_option('use_graph', 0)
         gpmc.set_option('tail_spin_limit', 0)
         p2 = gp['core'].LogMarginalPlan(x, g, 'rbf')
-        with pytest.raises(_lib.GpmcError, match='timed out'):
+        with pytest.raises(_lib.GpmcError, match='timed out') as ei:
             p2(hyp)
         torch.cuda.synchronize()                       # the aborted launch has drained
+        # the code names the wait that ran out: an operand tile or a diagonal factor of one of the 16 tile columns (no
+        # GEMM runs beside a one-launch problem), never the anonymous -1001
+        import re
+        code = int(re.search(r'info=(-\d+)', str(ei.value)).group(1))
+        cause, col = _lib.decode_timeout(code)
+        assert cause in (2, 3) and 0 <= col < 16, (code, cause, col)
+        assert _lib.TAIL_WAIT_CAUSES[cause].split()[1] in str(ei.value)
         gpmc.set_option('tail_spin_limit', 1 << 20)
         assert p2(hyp) == good
         p2.close()

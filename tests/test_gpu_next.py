@@ -221,21 +221,73 @@ def test_two_ranks_run_independent_device_chains(tmp_path):
     assert r.stdout.count('ok') == 2
 
 
-def test_two_processes_share_one_card_at_full_size():
-    """Two ranks of the bench at N = 8192 on ONE card (gloo; the driver's real launches have a card per rank): each rank's
-    tile-DAG launches compete with the other's for CU slots.  With pair roles tied to block indices (and so to XCDs)
-    this ended in the kernel's spin limit (info = -1001) about once in seven runs; with unclaimed pair roles taken over by
-    the grid's next blocks (csrc/tail.h) both ranks finish and the line is whole-job throughput of two ranks."""
+@pytest.mark.parametrize('n', [8192, 12288])
+def test_two_processes_share_one_card_at_full_size(n):
+    """Two ranks of the bench on ONE card (gloo; the driver's real launches have a card per rank), once at N = 8192 and
+    once at N = 12288 -- the sizes where round 2 recorded info = -1001 with 512-column panels (14 of 24 runs at 8192,
+    1 of 3 at 12288 even with 384-column panels).  Cause: a look-ahead panel launch gated on the flags of a GEMM that has
+    not been dispatched holds CU slots while it spins, and two processes' gated launches (2 x 264 workgroups) hold all
+    512, so neither GEMM can place a block.  ``chains.init_distributed`` now sets ``shared_card`` when ranks outnumber
+    cards and the hand-over becomes stream-ordered (csrc/potrf.hip): no workgroup waits for an unscheduled kernel.  One
+    run per size, on the default 512-column schedule; a timeout would name its wait (tests below)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPMC_DIST_BACKEND='gloo')
     env.pop('RANK', None), env.pop('WORLD_SIZE', None), env.pop('LOCAL_RANK', None)
-    for attempt in range(2):
-        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '8', '--warmup', '2',
-                            '--metric-only'], env=env, capture_output=True, text=True, timeout=280)
-        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
-        line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-        d = json.loads(line)
-        assert d['n_gpus'] == 2 and d['value'] > 0, d
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+                        '--metric-only', '--n', str(n)], env=env, capture_output=True, text=True, timeout=290)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['value'] > 0, d
+    assert d['config']['shared_card'] == 1, d['config']
+
+
+_NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'gaussianprocess-mcmc_amd'))
+import numpy as np, torch, torch.distributed as dist
+from gpmc import chains
+rank, world = chains.init_distributed()
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == 'nccl', dist.get_backend()
+dev = torch.device('cuda', torch.cuda.current_device())
+dist.barrier(device_ids=[dev.index])
+t = torch.tensor([3.25], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 3.25
+rng = np.random.RandomState(5)
+hh, hf = rng.standard_normal((3, 12)), rng.standard_normal((40, 12))
+allh, allf = chains.gather_histories(hh, hf)            # CUDA-tensor all_gather over RCCL
+assert allh.shape == (1, 3, 12) and np.array_equal(allh[0], hh) and np.array_equal(allf[0], hf)
+v = np.array([1.0, np.nan, 2.5])
+got = chains.gather_vector(v)
+assert np.array_equal(got[[0, 2]], v[[0, 2]]) and np.isnan(got[1])
+dist.destroy_process_group()
+print('nccl ok', flush=True)
+'''
+
+
+def test_rccl_path_executes_on_one_gpu(tmp_path):
+    """SURVEY.md 8(e): the RCCL branch of the chain driver (``backend='nccl', device_id=dev``, ``dist.barrier(device_ids=)``,
+    CUDA-tensor ``all_reduce`` / ``all_gather``) run for real on this box's one GPU: GPMC_FORCE_DIST=1 makes
+    ``init_distributed`` create the group for a single rank.  Then ``bench.py --gpus 1`` under the same flag -- its
+    barrier / max-over-ranks all_reduce go through RCCL -- must print its usual line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'nccl_worker.py'
+    script.write_text(_NCCL_WORKER % {'root': root})
+    env = dict(os.environ, GPMC_FORCE_DIST='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', LOCAL_WORLD_SIZE='1',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('GPMC_DIST_BACKEND', None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and 'nccl ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    env['MASTER_PORT'] = '29543'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
+                        '--metric-only', '--n', '2048'], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['config']['collective_backend'] == 'nccl', d['config']

@@ -179,6 +179,12 @@ def test_seeded_chain_at_the_reference_sizes(golden_dir, gp, name, min_same, rec
     same = ntries == z['ntries']
     first = int(z['iters']) if same.all() else int(np.argmin(same))
     record_property('first_divergent_iteration', first)
+    # the observed value is kept: gpurun_out/ travels back from the GPU box and is copied to profiles/ per round
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, 'first_divergent_iteration.txt'), 'a') as fh:
+            fh.write('%s: iterations %d, device follows the reference run for %d (asserted >= %d); proposals per iteration '
+                     'device %s reference %s\n' % (name, int(z['iters']), first, min_same, ntries.tolist(), z['ntries'].tolist()))
     assert first >= min_same, (first, ntries, z['ntries'])
     np.testing.assert_allclose(histHyp[:, :first], z['histHyp'][:, :first], rtol=1e-9)
     np.testing.assert_allclose(histF[:, :first], z['histF'][:, :first], rtol=0, atol=5e-2)
