@@ -500,7 +500,7 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
     try:
         gpmc.set_option('replay_form', form)
         plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
-        before = [plan(hyp) for _ in range(2)]
+        before = [plan(hyp) for _ in range(3)]                   # eager, eager (the yardstick), recorded
         L = _lib.lib()
         nops, ngr = ctypes.c_int(), ctypes.c_int()
         _lib.check(L.gpmc_debug_plan_ops(plan._h, ctypes.byref(nops), ctypes.byref(ngr)), 'gpmc_debug_plan_ops')
@@ -518,7 +518,7 @@ def test_recorded_sequence_survives_device_sync_then_destroy(gp, form):
         else:
             assert (parked1, nodes1) == (parked0, nodes0)
         after = plan(hyp)                                        # re-records after the churn dropped the sequence
-        assert after == before[0] == before[1]
+        assert after == before[0] == before[1] == before[2]
         ref = sds_ref.gp_log_marginal(x, g, hyp)
         assert abs(after - ref) <= 1e-10 * abs(ref)
         torch.cuda.synchronize()                                 # device-wide sync right before the destroy
