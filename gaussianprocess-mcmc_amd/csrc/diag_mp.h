@@ -12,6 +12,11 @@
 //      each) per slab.  MFMA operand maps (measured, scripts/mfma_probe.hip):
 //      A[i][k] lane 16k+4blk+i, B[k][j] lane 16k+4blk+j, D[i][j] lane 16i+4blk+j.
 // f64 only (the f32 path keeps the generic kernels).
+// Measured and not kept (round 3): 4-column micro-panels -- half the serial VALU stream per 64 columns (16 x (4 rsq chains +
+// 6 updates + 20 readlanes) instead of 8 x (8 + 28 + 72); the updates of columns 4..7 by 0..3 become one more MFMA per
+// slab) for twice the barriers and extractions: correct (all kernel tests), N = 2048 / 4096 / 8192 0.587 / 1.203 / 4.262 ms
+// against 0.573-0.583 / 1.186-1.193 / 4.234-4.27: the two barriers and the LDS round trip of a micro-step cost what the
+// shorter stream saves.
 #pragma once
 #include "gpmc_common.h"
 

@@ -183,6 +183,21 @@ int unpack_lower(const T* W, int np_, int ldw, T* L, int n, int ldl, hipStream_t
 template <typename T>
 int unpack_rows(const T* W, int np_, int ldw, T* B, int nrhs, int n, int ldb, hipStream_t s);
 template <typename T>
+int reset_tri(T* R, int np_, int ld, const T* diag_dev, hipStream_t s);
+template <typename T>
+int veccopy(T* dst, const T* src, int n, hipStream_t s);
+template <typename T>
+int publish_host(const double* out4, const int* info2, const T* vec, int n, double* host_mapped, hipStream_t s);
+// a caller's launch sequence (library launches and the caller's own kernels on one stream) recorded and replayed:
+// gpmc_seq_* in plan.hip; retirement follows the same rule as the plans' execs (graveyard on runtimes < 7.2)
+struct Seq {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipStream_t stream = nullptr;
+    bool capturing = false;
+};
+int seq_retire(Seq* q);
+template <typename T>
 int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_, int ldc,
               hipStream_t s);
 template <typename T>

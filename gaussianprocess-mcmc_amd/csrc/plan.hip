@@ -292,6 +292,52 @@ int gpmc_potrf_tri_f64(double* W, int mp, int np_, int ldw, int ntri, int* info_
 int gpmc_potrf_tri_f32(float* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch, gpmc_stream_t stream) {
     return potrf<float>(W, mp, np_, ldw, info_dev, scratch, S_(stream), ntri);
 }
+int gpmc_veccopy_f64(double* dst, const double* src, int n, gpmc_stream_t stream) { return veccopy<double>(dst, src, n, S_(stream)); }
+int gpmc_veccopy_f32(float* dst, const float* src, int n, gpmc_stream_t stream) { return veccopy<float>(dst, src, n, S_(stream)); }
+int gpmc_publish_host_f64(const double* out4, const int* info2, const double* vec, int n, double* host_mapped, gpmc_stream_t stream) {
+    return publish_host<double>(out4, info2, vec, n, host_mapped, S_(stream));
+}
+int gpmc_publish_host_f32(const double* out4, const int* info2, const float* vec, int n, double* host_mapped, gpmc_stream_t stream) {
+    return publish_host<float>(out4, info2, vec, n, host_mapped, S_(stream));
+}
+
+/* ---- a caller's launch sequence, recorded once and replayed (the SDS proposal: gpmc/sds.py) ---- */
+int gpmc_seq_begin(gpmc_seq** out, gpmc_stream_t stream) {
+    GPMC_ARG(out != nullptr, 1);
+    GPMC_ARG(stream != nullptr, 2);                 /* the NULL stream cannot be captured */
+    Seq* q = new (std::nothrow) Seq();
+    if (!q) return fail(-1, "gpmc_seq_begin: out of host memory");
+    q->stream = S_(stream);
+    hipError_t e = hipStreamBeginCapture(q->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { delete q; return fail((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    q->capturing = true;
+    *out = reinterpret_cast<gpmc_seq*>(q);
+    return 0;
+}
+int gpmc_seq_end(gpmc_seq* h) {
+    Seq* q = reinterpret_cast<Seq*>(h);
+    GPMC_ARG(q != nullptr && q->capturing, 1);
+    q->capturing = false;
+    hipError_t e = hipStreamEndCapture(q->stream, &q->graph);
+    if (e != hipSuccess) { q->graph = nullptr; return fail((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&q->exec, q->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { q->exec = nullptr; return fail((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    return 0;
+}
+int gpmc_seq_launch(gpmc_seq* h, gpmc_stream_t stream) {
+    Seq* q = reinterpret_cast<Seq*>(h);
+    GPMC_ARG(q != nullptr && q->exec != nullptr, 1);
+    GPMC_HIP(hipGraphLaunch(q->exec, S_(stream)));
+    return 0;
+}
+int gpmc_seq_retire(gpmc_seq* h) { return seq_retire(reinterpret_cast<Seq*>(h)); }
+
+int gpmc_reset_tri_f64(double* R, int np_, int ld, const double* diag_dev, gpmc_stream_t stream) {
+    return reset_tri<double>(R, np_, ld, diag_dev, S_(stream));
+}
+int gpmc_reset_tri_f32(float* R, int np_, int ld, const float* diag_dev, gpmc_stream_t stream) {
+    return reset_tri<float>(R, np_, ld, diag_dev, S_(stream));
+}
 int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int n, int np_, int ldc, gpmc_stream_t stream) {
     return syrk_tri<double>(P, ldp, diag_add, C, n, np_, ldc, S_(stream));
 }

@@ -43,7 +43,26 @@ thread_local char g_err[512] = {0};
 
 unsigned long long* g_tail_dbg = nullptr;    // diagnostic only (gpmc_debug_tail_stamps): stamp buffer of the next launches
 static size_t potrf_scratch_base(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
-size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + TAIL_SYNC_BYTES; }
+size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + TAIL_SYNC_BYTES + 64; }
+
+// ======================================================================= zeroing of sync / info words
+// A kernel, not hipMemsetAsync: in a replayed launch sequence that holds several memset nodes, HIP runtime 7.0.51831
+// fills with a wrong value from the second replay on (the words came back as 0xa5a5a5a5: the tile-DAG kernel then saw a
+// raised abort word and left at once -- the SDS proposal sequence with its two factorisations, round 3, DESIGN.md section 4;
+// the log-marginal plan's sequences hold one memset node and never showed it).  One launch also clears the info word.
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, unsigned nquads, int* __restrict__ info) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nquads) reinterpret_cast<u4*>(p)[i] = u4{0u, 0u, 0u, 0u};
+    if (info != nullptr && i == 0) *info = 0;
+}
+static int zero_words(unsigned* p, size_t bytes, int* info, hipStream_t s) {       // p 16-byte aligned, bytes a multiple of 16
+    const unsigned nquads = (unsigned)(bytes / 16);
+    const unsigned grid = nquads ? (nquads + 255u) / 256u : 1u;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, s, p, nquads, info);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
 
 // ======================================================================= diagonal block
 // Factor the 64x64 block at Wd (lower triangle read) in LDS and write L back (strict upper = 0).
@@ -647,7 +666,10 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     const int la_pad = (np_ >= 8192) ? 0 : 16000;
     const int pad_serial = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
     const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
-    if (!(sc && sc->info_cleared)) GPMC_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), s));
+    if (!(sc && sc->info_cleared)) {
+        int rcz = zero_words(nullptr, 0, info_dev, s);
+        if (rcz) return rcz;
+    }
 
     // the last columns as one tile-DAG launch (tail.h): f64
     // (float storage: the kernel converts on load / store, its arithmetic is f64 as in the panel kernels; the f32 trailing
@@ -674,10 +696,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if (!sync_zeroed) sync_next = 0;
         if ((sync_next + words) * sizeof(unsigned) > TAIL_SYNC_BYTES) return fail(-1, "potrf: sync region overflow");
         unsigned* sync = dag_sync + sync_next;
-        if (!sync_zeroed) {     // (rounded up to 1 KiB inside the reserve: the runtime splits an odd-sized fill into two kernels)
-            size_t zb = (words * sizeof(unsigned) + 1023) & ~(size_t)1023;
-            if ((sync_next * sizeof(unsigned)) + zb > TAIL_SYNC_BYTES) zb = words * sizeof(unsigned);
-            GPMC_HIP(hipMemsetAsync(sync, 0, zb, st));
+        if (!sync_zeroed) {     // (sync_next is 0 here: an aligned start; the scratch reserve has 64 bytes of slack for the round-up)
+            int rcz = zero_words(sync, (words * sizeof(unsigned) + 15) & ~(size_t)15, nullptr, st);
+            if (rcz) return rcz;
         }
         sync_next += words;
         static bool attr_done = false;   // per T instantiation
@@ -844,9 +865,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 k0 = k1;
             }
             if (total * sizeof(unsigned) <= TAIL_SYNC_BYTES) {
-                size_t zb = (total * sizeof(unsigned) + 1023) & ~(size_t)1023;      // (one fill kernel instead of two)
-                if (zb > TAIL_SYNC_BYTES) zb = total * sizeof(unsigned);
-                GPMC_HIP(hipMemsetAsync(dag_sync, 0, zb, s));
+                const size_t zb = (total * sizeof(unsigned) + 15) & ~(size_t)15;
+                int rcz = zero_words(dag_sync, zb, nullptr, s);
+                if (rcz) return rcz;
                 sync_zeroed = true;
             }
         }

@@ -92,6 +92,72 @@ __global__ void unpack_rows_kernel(const T* __restrict__ W, int np_, int ldw, T*
     B[(size_t)r * ldb + j] = W[(size_t)(np_ + r) * ldw + j];
 }
 
+// rows (np_ x np_, ld) <- upper-trapezoidal s I: the diagonal becomes *diag_dev, everything right of it zero, the strict lower
+// part is NOT touched.  The riding block of gpmc_potrf_tri comes back as P = s L^-T, zero left of the diagonal and never
+// written there, so re-arming it for the next proposal only has to clear the upper triangle: half of the full memset
+// (268 instead of 537 MB at N = 8192), one launch instead of a fill and a diagonal scatter, and the diagonal value comes
+// from device memory, so the launch can sit in a recorded sequence.  One workgroup per 64-row x 256-column piece.
+template <typename T>
+__global__ void __launch_bounds__(256)
+reset_tri_kernel(T* __restrict__ R, int np_, int ld, const T* __restrict__ diag_dev) {
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 256;
+    if (c0 + 256 <= r0) return;                      // entirely left of the diagonal
+    const T dv = *diag_dev;
+    const int c = c0 + threadIdx.x;
+    for (int r = r0; r < r0 + 64; ++r)
+        if (c >= r && c < np_) R[(size_t)r * ld + c] = (c == r) ? dv : (T)0;
+}
+template <typename T>
+int reset_tri(T* R, int np_, int ld, const T* diag_dev, hipStream_t s) {
+    GPMC_ARG(R != nullptr && np_ > 0 && np_ % 64 == 0 && ld >= np_, 1);
+    GPMC_ARG(diag_dev != nullptr, 4);
+    hipLaunchKernelGGL((reset_tri_kernel<T>), dim3((np_ + 255) / 256, np_ / 64), dim3(256), 0, s, R, np_, ld, diag_dev);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template int reset_tri<double>(double*, int, int, const double*, hipStream_t);
+template int reset_tri<float>(float*, int, int, const float*, hipStream_t);
+
+// dst[0:n] = src[0:n] as a kernel (a recorded sequence then holds no memcpy node: kernels and memsets only, like the plan's)
+template <typename T>
+__global__ void __launch_bounds__(256) veccopy_kernel(T* __restrict__ dst, const T* __restrict__ src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+template <typename T>
+int veccopy(T* dst, const T* src, int n, hipStream_t s) {
+    GPMC_ARG(dst != nullptr && src != nullptr && n > 0, 1);
+    hipLaunchKernelGGL((veccopy_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template int veccopy<double>(double*, const double*, int, hipStream_t);
+template int veccopy<float>(float*, const float*, int, hipStream_t);
+
+// The results of one SDS proposal straight into pinned, device-mapped host memory (no copy node after the sequence):
+// host[0..3] = out4 (G, log det, quadratic form, info of the first factorisation), host[4] = *info2, host[8 .. 8 + n) = vec.
+template <typename T>
+__global__ void __launch_bounds__(256)
+publish_host_kernel(const double* __restrict__ out4, const int* __restrict__ info2, const T* __restrict__ vec, int n,
+                    double* __restrict__ host) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) host[8 + i] = (double)vec[i];
+    if (i < 4) host[i] = out4[i];
+    if (i == 4) host[4] = (double)info2[0];
+    __threadfence_system();
+}
+template <typename T>
+int publish_host(const double* out4, const int* info2, const T* vec, int n, double* host_mapped, hipStream_t s) {
+    GPMC_ARG(out4 != nullptr && info2 != nullptr && vec != nullptr && n > 0, 1);
+    GPMC_ARG(host_mapped != nullptr, 5);
+    hipLaunchKernelGGL((publish_host_kernel<T>), dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, s, out4, info2,
+                       vec, n, host_mapped);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template int publish_host<double>(const double*, const int*, const double*, int, double*, hipStream_t);
+template int publish_host<float>(const double*, const int*, const float*, int, double*, hipStream_t);
+
 template <typename T>
 int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s) {
     GPMC_ARG(A && n > 0 && lda >= n, 1);

@@ -203,6 +203,29 @@ int Sched::drop_ops() {
     return rc;
 }
 
+// a caller-recorded sequence (plan.hip, gpmc_seq_*): it may span the look-ahead's two streams, so it leaves like a
+// fork/join exec
+int seq_retire(Seq* q) {
+    if (!q) return 0;
+    int rc = 0;
+    if (q->exec) {
+        if (forkjoin_destroy_unsafe()) {
+            Graveyard& g = graveyard();
+            std::lock_guard<std::mutex> lk(g.mu);
+            size_t n = 0;
+            if (q->graph && hipGraphGetNodes(q->graph, nullptr, &n) == hipSuccess) g.nodes += n;
+            g.execs.push_back(q->exec);
+            if (q->graph) g.graphs.push_back(q->graph);
+        } else {
+            hipError_t e = hipGraphExecDestroy(q->exec);
+            if (e != hipSuccess) rc = fail((int)e, "hipGraphExecDestroy: %s", hipGetErrorString(e));
+            if (q->graph) (void)hipGraphDestroy(q->graph);
+        }
+    }
+    delete q;
+    return rc;
+}
+
 int Sched::destroy() {
     int rc = drop_ops();
     for (hipEvent_t e : events) (void)hipEventDestroy(e);

@@ -61,6 +61,11 @@ def _sig(lib):
         'gpmc_unpack_rows_f64': ([P, I, I, P, I, I, I, P], I), 'gpmc_unpack_rows_f32': ([P, I, I, P, I, I, I, P], I),
         'gpmc_potrf_tri_f64': ([P, I, I, I, I, P, P, P], I),
         'gpmc_potrf_tri_f32': ([P, I, I, I, I, P, P, P], I),
+        'gpmc_reset_tri_f64': ([P, I, I, P, P], I), 'gpmc_reset_tri_f32': ([P, I, I, P, P], I),
+        'gpmc_veccopy_f64': ([P, P, I, P], I), 'gpmc_veccopy_f32': ([P, P, I, P], I),
+        'gpmc_publish_host_f64': ([P, P, P, I, P, P], I), 'gpmc_publish_host_f32': ([P, P, P, I, P, P], I),
+        'gpmc_seq_begin': ([ctypes.POINTER(c_void_p), P], I), 'gpmc_seq_end': ([P], I),
+        'gpmc_seq_launch': ([P, P], I), 'gpmc_seq_retire': ([P], I),
         'gpmc_syrk_tri_f64': ([P, I, c_double, P, I, I, I, P], I),
         'gpmc_syrk_tri_f32': ([P, I, c_float, P, I, I, I, P], I),
         'gpmc_syrk_diff_f64': ([P, I, P, I, I, c_double, P, I, I, I, P], I),
@@ -106,6 +111,10 @@ def lib():
     """The loaded library; raises GpmcError when it has not been built."""
     global _lib, EXPORTS
     if _lib is None:
+        # torch first: libgpmc.so must bind to the HIP runtime torch loads (its bundled one), not open a second copy of
+        # the runtime beside it -- two runtimes in one process do not see each other's device
+        # ("no ROCm-capable device is detected" from whichever came second)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise GpmcError('libgpmc.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
                             '(there is no CPU fallback)' % LIB_PATH)

@@ -90,6 +90,22 @@ def potrf_tri(W, mp, np_, ntri, info, scratch):
                                     stream_ptr()), 'gpmc_potrf_tri')
 
 
+def reset_tri(rows, np_, diag_dev):
+    """rows <- upper-trapezoidal (diag_dev[0]) I: diagonal set, zero right of it, strict lower part untouched"""
+    check(_fn('reset_tri', rows.dtype)(rows.data_ptr(), np_, rows.stride(0), diag_dev.data_ptr(), stream_ptr()),
+          'gpmc_reset_tri')
+
+
+def veccopy(dst, src, n):
+    check(_fn('veccopy', dst.dtype)(dst.data_ptr(), src.data_ptr(), n, stream_ptr()), 'gpmc_veccopy')
+
+
+def publish_host(out4, info2, vec, n, host_pinned):
+    """out4, *info2 and vec[0:n] into pinned host memory (float64 tensor of >= 8 + n, device-mapped): no copy node"""
+    check(_fn('publish_host', vec.dtype)(out4.data_ptr(), info2.data_ptr(), vec.data_ptr(), n, host_pinned.data_ptr(),
+                                         stream_ptr()), 'gpmc_publish_host')
+
+
 def logdet_quad(W, n, alpha, info, out):
     check(_fn('logdet_quad', W.dtype)(W.data_ptr(), n, W.stride(0), alpha.data_ptr(),
                                       0 if info is None else info.data_ptr(), out.data_ptr(), stream_ptr()),

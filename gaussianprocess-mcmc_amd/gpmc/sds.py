@@ -16,6 +16,11 @@ scalar) and A = K + S = L L^T:   R = K - V^T V = K - K A^-1 K  ==  S - S A^-1 S 
     row np_ = f - m ; gpmc_potrf(R) -> C = chol(R + 1e-11 I), eta = C^-1 (f - m)                              (a7, a9)
     f' = gpmc_trmv_lower(C, eta) + m                                                                          (a10)
 
+One proposal of the sampler's inner loop (sliceSample.py:136-147) is ``SDSWorkspace.proposal(hyp)``: the whole sequence
+above plus f' and the five scalars into pinned host memory, recorded once (stream capture) and replayed, one stream
+synchronisation per proposal; the jitter schedules of both factorisations run eagerly when the replayed happy path
+reports a failed pivot.
+
 Form ``'syrk'`` is the first implementation (8 N^3 / 3): K itself rides on the factorisation (V^T = K L^-T, N^3) and
 R = K - V^T V is a full SYRK (N^3); kept for cross-checks.  Both follow the reference's seeded chains decision for
 decision (tests/test_gpu_sds.py); the reference itself spends ~11.3 N^3 flops here (dense S, LU solves, two inverses).
@@ -52,15 +57,32 @@ class SDSWorkspace(object):
         self.WR = torch.zeros((self.mpR, np_), dtype=dtype, device=dev)
         self.infoA = torch.zeros(1, dtype=torch.int32, device=dev)
         self.infoR = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one scratch per factorisation: each holds the sync words of its tile-DAG launches, zeroed by a memset in front of
+        # the launch -- and in a REPLAYED sequence (HIP runtime 7.0) a memset node is not reliably ordered behind the
+        # kernel node before it: with one shared scratch the second factorisation's memset cleared the flags of the first
+        # one's running kernel from the second replay on (round 3).  With a region of its own every memset
+        # only has to precede its own kernel.
         self.scratch = ops.potrf_scratch(np_, dev)
+        self.scratchR = ops.potrf_scratch(np_, dev)
         self.out = torch.zeros(4, dtype=torch.float64, device=dev)
-        self.kpS = torch.zeros(2 + (1 if kernel == 'rbf' else self.d), dtype=dtype, device=dev)
-        self.kp0 = torch.zeros_like(self.kpS)
+        nk = 2 + (1 if kernel == 'rbf' else self.d)
+        self.kp_dev = torch.zeros(2 * nk, dtype=dtype, device=dev)      # [kpS | kp0], staged by ONE copy from pinned memory
+        self.kp_host = torch.zeros(2 * nk, dtype=dtype).pin_memory()
+        self.kpS, self.kp0 = self.kp_dev[:nk], self.kp_dev[nk:]
         self.m = torch.zeros(n, dtype=dtype, device=dev)
         self.gs = torch.zeros(n, dtype=dtype, device=dev)
         self.prop_f = torch.zeros(n, dtype=dtype, device=dev)
         self.Rdiag = torch.zeros(n, dtype=dtype, device=dev)
         self.R0 = None                                            # copy of R for the jitter schedule, allocated on first use
+        # inputs of the recorded proposal sequence (fixed addresses) and its results in pinned host memory
+        self.f_in = torch.zeros(n, dtype=dtype, device=dev)
+        self.g_in = torch.zeros(n, dtype=dtype, device=dev)
+        self.ita_in = torch.zeros(n, dtype=dtype, device=dev)
+        self.res_host = torch.zeros(8 + n, dtype=torch.float64).pin_memory()     # [G, logdet, quad, infoA, infoR, -, -, -, f'...]
+        self._seq = None
+        self._seq_stream = None
+        self._proposals = 0
+        self._dirty = False        # a failed factorisation of K + S has run: its riding rows may hold NaN anywhere
 
     # ------------------------------------------------------------------ pieces
     def _set_hyp(self, hyp):
@@ -69,12 +91,16 @@ class SDSWorkspace(object):
         self.Sii = covK.s_diag_scalar(kp[0], sn)        # S = Sii * I : the kernel diagonal is the constant sf2
         kp0 = kp.copy()
         kp[1] = self.Sii
-        self.kpS.copy_(torch.as_tensor(kp, dtype=self.dtype))
-        self.kp0.copy_(torch.as_tensor(kp0, dtype=self.dtype))
+        self._kp0_sf2 = float(kp0[0])
+        nk = kp.shape[0]
+        self.kp_host[:nk] = torch.as_tensor(kp, dtype=self.dtype)
+        self.kp_host[nk:] = torch.as_tensor(kp0, dtype=self.dtype)
+        self.kp_dev.copy_(self.kp_host, non_blocking=True)       # one H2D from pinned memory, ordered on the current stream
 
-    def _factor_A(self, g, jitter):
+    def _factor_A(self, jitter):
         """K + S (+ jitter) with g and either s I ('inv') or K ('syrk') riding: L, alpha = L^-1 g and P = s L^-T or
-        V^T = K L^-T, then the log-marginal reduction"""
+        V^T = K L^-T, then the log-marginal reduction.  No host value enters a launch (the diagonal shift is read from
+        kpS[1] on the device), so the same calls can be recorded."""
         n, np_ = self.n, self.np_
         if jitter:
             self.kpS[1] = self.Sii + jitter
@@ -82,24 +108,34 @@ class SDSWorkspace(object):
         ops.kbuild(self.kernel, self.X, self.kpS, self.WA, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
         rows = self.WA[self.rows0:self.rows0 + np_]
         if self.form == 'inv':
-            rows.zero_()                                          # last proposal's P; O(N^2) memset
-            torch.diagonal(rows).fill_(self._sA)
+            self._clean()
+            ops.reset_tri(rows, np_, self.kpS[1:2])               # last proposal's P -> s I (upper triangle only)
         else:
             ops.kbuild(self.kernel, self.X, self.kp0, rows, np_, np_, ops.KB_FULL)
-        self.WA[self.g_row, :n].copy_(g)
+        ops.veccopy(self.WA[self.g_row], self.g_in, n)           # (a kernel, not a copy node: see _record)
         if self.form == 'inv':
             ops.potrf_tri(self.WA, self.mpA, np_, np_, self.infoA, self.scratch)
         else:
             ops.potrf(self.WA, self.mpA, np_, self.infoA, self.scratch)
         ops.logdet_quad(self.WA, n, self.WA[self.g_row], self.infoA, self.out)
 
-    def _make_R(self, g):
-        """R = K - V^T V (= S - S A^-1 S) into WR (no shift yet), m = R S^-1 g, and diag(R) saved for the jitter
+    def _clean(self):
+        """A factorisation that met a non-positive pivot keeps running on NaN, and 0 * NaN turns the structural zeros of
+        the riding rows (left of P's diagonal, the rest of the g block) into NaN; ``gpmc_reset_tri`` only re-arms the
+        upper triangle, so after a failure everything below the matrix is cleared once, eagerly."""
+        if self._dirty:
+            self.WA[self.np_:].zero_()
+            self._dirty = False
+
+    def _make_R(self):
+        """R = K - V^T V (= S - S A^-1 S) into WR (no 1e-11 shift yet), m = R S^-1 g, and diag(R) saved for the jitter
         schedule (the in-place factorisation destroys it)"""
         n, np_ = self.n, self.np_
+        g = self.g_in
         rows = self.WA[self.rows0:self.rows0 + np_]
         if self.form == 'inv':
-            ops.syrk_tri(rows, self.WR, n, np_, self._sA)
+            ops.syrk_tri(rows, self.WR, n, np_, 0.0)              # -P P^T (identity on the padding) ...
+            self.WR.diagonal()[:n].add_(self.kpS[1])              # ... + s_A I, the shift read on the device
             # m = R S^-1 g = (s_A I - P P^T) g / s = (s_A / s)(g - P alpha), alpha = L^-1 g the riding row (P^T g = s_A alpha):
             # one triangular product, R itself is not read.  s_A = s unless K + S needed jitter.
             ops.trmv_upper(rows, n, self.WA[self.g_row], g, -1.0, self.m)
@@ -112,42 +148,61 @@ class SDSWorkspace(object):
             ops.symv_lower(self.WR, n, self.gs, self.m)
         self.Rdiag.copy_(self.WR.diagonal()[:n])
 
-    def _chol_R(self, f, need_eta, jitter):
+    def _chol_R(self, jitter):
         """C = chol(R + (1e-11 + jitter) I) in place, eta = C^-1 (f - m) riding"""
         n, np_ = self.n, self.np_
         self.WR.diagonal()[:n].add_(R_JITTER + jitter)
-        if need_eta:
-            torch.sub(f, self.m, out=self.WR[np_, :n])
-        else:
-            self.WR[np_, :n].zero_()
-        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratch)
+        torch.sub(self.f_in, self.m, out=self.WR[np_, :n])
+        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratchR)
+
+    def _results(self):
+        """[G, logdet, quad, infoA], infoR and f' -> pinned host memory, written by a kernel (asynchronous; read after a
+        stream synchronisation)"""
+        ops.publish_host(self.out, self.infoR, self.prop_f, self.n, self.res_host)
+
+    def _read(self):
+        torch.cuda.current_stream().synchronize()                # the one sync of the happy path
+        r = self.res_host
+        return float(r[0]), _lib.check_info(r[3]), _lib.check_info(r[4])
 
     def aux_var_model(self, f, hyp, g, need_eta, maxtries=5):
         """Factor everything for hyper-parameters ``hyp`` given latent f and auxiliary g (device vectors).
 
         Returns G = log N(g; 0, K + S); afterwards self.m, the lower triangle of self.WR (= chol_R_theta),
-        self.eta (if need_eta) and self.WA (L, alpha, and P = s L^-T or V^T) are valid.  A failed factorisation follows
+        self.eta and self.WA (L, alpha, and P = s L^-T or V^T) are valid.  A failed factorisation follows
         the jitchol schedule the reference pins (pyGPs 1.3.4): mean(diag) * 1e-9 added, x10 per retry, ``maxtries``
         retries, then np.linalg.LinAlgError propagates to the caller exactly as in the reference.  R has eigenvalues at
         rounding level, so that schedule is part of normal operation (about a third of the bench's points at N = 8192):
-        on a failure R is rebuilt once (the factorisation is in place), kept, and restored for every further retry."""
+        on a failure R is rebuilt once (the factorisation is in place), kept, and restored for every further retry.
+        (``need_eta`` is kept for the signature: eta rides on the factorisation of R either way.)"""
+        if f is not self.f_in:
+            self.f_in.copy_(f)
+        if g is not self.g_in:
+            self.g_in.copy_(g)
+        self._retried = False
         self._set_hyp(hyp)
-        self._factor_A(g, 0.0)
-        self._make_R(g)
-        self._chol_R(f, need_eta, 0.0)
-        res = self.out.cpu().numpy()                             # the one sync of the happy path (scalars)
-        infoA, infoR = _lib.check_info(res[3]), _lib.check_info(self.infoR.item())
+        self._factor_A(0.0)
+        self._make_R()
+        self._chol_R(0.0)
+        self._results()
+        return self._finish(maxtries)
+
+    def _finish(self, maxtries=5):
+        """read the results of the happy-path sequence (eager or replayed) and run the jitter schedules if it failed"""
+        G, infoA, infoR = self._read()
         if infoA != 0:
-            diag_mean = float(self.kp0[0]) + self.Sii            # diag(K + S) is constant and positive
+            self._dirty = True
+            diag_mean = self._kp0_sf2 + self.Sii                 # diag(K + S) is constant and positive
             jitter = diag_mean * 1e-9
             for _ in range(maxtries):
-                self._factor_A(g, jitter)
-                self._make_R(g)
-                self._chol_R(f, need_eta, 0.0)
-                res = self.out.cpu().numpy()
-                infoA, infoR = _lib.check_info(res[3]), _lib.check_info(self.infoR.item())
+                self._factor_A(jitter)
+                self._make_R()
+                self._chol_R(0.0)
+                self._results()
+                G, infoA, infoR = self._read()
                 if infoA == 0:
                     break
+                self._dirty = True
                 jitter *= 10.
             else:
                 raise np.linalg.LinAlgError('not positive definite, even with jitter.')
@@ -156,20 +211,100 @@ class SDSWorkspace(object):
             if not rdiag_mean > 0:
                 raise np.linalg.LinAlgError('not pd: non-positive diagonal elements')
             jitter = rdiag_mean * 1e-9
-            self._make_R(g)                                      # the failed attempt overwrote R
+            self._make_R()                                       # the failed attempt overwrote R
             if self.R0 is None:
                 self.R0 = torch.empty((self.np_, self.np_), dtype=self.dtype, device=self.WR.device)
             self.R0.copy_(self.WR[:self.np_])
             for t in range(maxtries):
                 if t:
                     self.WR[:self.np_].copy_(self.R0)
-                self._chol_R(f, need_eta, jitter)
+                self._chol_R(jitter)
                 if _lib.check_info(self.infoR.item()) == 0:
                     break
                 jitter *= 10.
             else:
                 raise np.linalg.LinAlgError('not positive definite, even with jitter.')
-        return float(res[0])
+            self._retried = True
+        return G
+
+    # ------------------------------------------------------------------ one proposal of the sampler's inner loop
+    def begin(self, f, g, ita):
+        """fix the iteration's latent f, auxiliary g and whitened latent eta (sliceSample.py:107-108): the proposals of
+        this iteration (sliceSample.py:131-163) only change the hyper-parameters"""
+        if f is not self.f_in:
+            self.f_in.copy_(f)
+        if g is not self.g_in:
+            self.g_in.copy_(g)
+        self.ita_in.copy_(ita)
+
+    def _sequence(self):
+        """the happy path of one proposal, without a host value in any launch and without a sync: K' + S' with g and
+        s I riding -> L', alpha', P' -> G'; R' = s I - P' P'^T, m'; chol(R' + 1e-11 I) with f - m' riding; f' = C' eta + m';
+        results and f' to pinned host memory"""
+        self._factor_A(0.0)
+        self._make_R()
+        self._chol_R(0.0)
+        ops.trmv_lower(self.WR, self.n, self.ita_in, self.m, self.prop_f)
+        self._results()
+
+    def _record(self):
+        """Record the proposal sequence once (``gpmc_seq_*``: stream capture around the same calls -- the library's
+        launches and torch's elementwise kernels go to the capturing stream, the look-ahead's second stream joins the
+        capture through its event edges) and replay it per proposal.  The sequence holds kernels and memsets only: a
+        first version with copy nodes in it (torch ``copy_`` of contiguous vectors, D2H copies of the results) replayed
+        out of order on HIP runtime 7.0 from the second replay on (round 3), hence ``gpmc_veccopy`` and
+        ``gpmc_publish_host``.  The exec is retired through the library's graveyard (csrc/sched.hip)."""
+        import ctypes
+        L = _lib.lib()
+        side = torch.cuda.Stream(device=self.X.device)
+        side.wait_stream(torch.cuda.current_stream())
+        h = ctypes.c_void_p()
+        with torch.cuda.stream(side):
+            _lib.check(L.gpmc_seq_begin(ctypes.byref(h), side.cuda_stream), 'gpmc_seq_begin')
+            try:
+                self._sequence()
+            finally:
+                rc = L.gpmc_seq_end(h)
+            _lib.check(rc, 'gpmc_seq_end')
+        torch.cuda.current_stream().wait_stream(side)
+        self._seq, self._seq_stream = h, side
+
+    def close(self):
+        if getattr(self, '_seq', None) is not None:
+            torch.cuda.synchronize()
+            _lib.lib().gpmc_seq_retire(self._seq)
+            self._seq = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def proposal(self, hyp, maxtries=5, record=True):
+        """(G', f') for proposed hyper-parameters: the reference's loop body sliceSample.py:136-147 (K build, aux_var_model
+        with the iteration's g, prop_f, propG).  The first proposal of a workspace launches eagerly, the second records
+        the sequence, later ones replay it: ONE stream synchronisation per proposal.  If a factorisation fails the
+        jitter schedules run eagerly, exactly as in ``aux_var_model``."""
+        self._set_hyp(hyp)
+        self._retried = False
+        self._sA = self.Sii              # the recorded sequence is the jitter-free path (the eager one sets it itself)
+        if self._seq is None and record and self._proposals >= 1 and self.form == 'inv':
+            self._clean()                                    # (not inside the recording)
+            torch.cuda.current_stream().synchronize()
+            self._record()
+        if self._seq is not None and record:
+            self._clean()
+            _lib.check(_lib.lib().gpmc_seq_launch(self._seq, ops.stream_ptr()), 'gpmc_seq_launch')
+        else:
+            self._sequence()
+        self._proposals += 1
+        G = self._finish(maxtries)
+        if self._retried or self._sA != self.Sii:
+            # a jitter retry re-factored R (or K + S) after the sequence had formed f': form it again from the final factors
+            ops.trmv_lower(self.WR, self.n, self.ita_in, self.m, self.prop_f)
+            return G, self.prop_f.cpu().numpy()
+        return G, self.res_host[8:8 + self.n].numpy().astype(np.float64, copy=True)
 
     @property
     def eta(self):

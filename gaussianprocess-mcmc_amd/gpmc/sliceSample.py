@@ -81,6 +81,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
 
     curG = ws.aux_var_model(f_dev, hyp, g, need_eta=True)
     ita = ws.eta.clone()
+    ws.begin(f_dev, g, ita)          # f, g and eta are fixed for the proposals of this iteration (sliceSample.py:131-163)
 
     v = np.random.uniform(low=0., high=scale)
     hyp_min = np.maximum(hyp - v, 0)
@@ -105,8 +106,7 @@ def surrogate_slice_sampling(f, x, y, hyp, scale, iter=0, workspace=None, stats=
         if iter < NOISE_FREEZE_ITERS:
             prop_hyp[2] = hyp[2]
 
-        propG = ws.aux_var_model(f_dev, prop_hyp, g, need_eta=False)   # LinAlgError propagates, as in the reference
-        prop_f = ws.propose_f(ita).cpu().numpy()
+        propG, prop_f = ws.proposal(prop_hyp)          # LinAlgError propagates, as in the reference
         lik_func.sn = prop_hyp[2]
         prop_llk = lik_func.evaluate(y=y - my, mu=prop_f)
         propPrior, _ = log_gamma(prop_hyp, PRIOR_K, PRIOR_THETA, True)

@@ -82,6 +82,28 @@ int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scra
  * returns s L^-T, i.e. the explicit inverse factor, for N^3/3 flops instead of the N^3 of a dense right-hand side:
  * those rows stay zero left of their diagonal, so every launch stops at the last row that can hold anything.
  * This is how the SDS block gets R = S - S (K+S)^-1 S (== K - V^T V, sliceSample.py:197-198) -- see gpmc_syrk_tri. */
+/* small companions of the SDS proposal sequence (gpmc/sds.py): a vector copy as a kernel, and the proposal's results --
+ * out4 (gpmc_logdet_quad), the second factorisation's info word and a vector (f') -- written straight into pinned,
+ * device-mapped host memory: host[0..3] = out4, host[4] = *info2, host[8 .. 8 + n) = vec (as doubles). */
+int gpmc_veccopy_f64(double* dst, const double* src, int n, gpmc_stream_t stream);
+int gpmc_veccopy_f32(float* dst, const float* src, int n, gpmc_stream_t stream);
+int gpmc_publish_host_f64(const double* out4, const int* info2, const double* vec, int n, double* host_mapped, gpmc_stream_t stream);
+int gpmc_publish_host_f32(const double* out4, const int* info2, const float* vec, int n, double* host_mapped, gpmc_stream_t stream);
+/* A caller's launch sequence -- library launches and the caller's own kernels, all on `stream` (the look-ahead's second
+ * stream joins through its event edges) -- recorded once and replayed: begin (stream capture starts; not the NULL
+ * stream), enqueue the sequence, end (instantiates), launch any number of times on any stream, retire.  The sequence
+ * must hold no host value that changes between replays and allocate nothing.  Retired like the plans' execs (parked on
+ * HIP runtimes < 7.2, see gpmc_graveyard_stats). */
+typedef struct gpmc_seq gpmc_seq;
+int gpmc_seq_begin(gpmc_seq** out, gpmc_stream_t stream);
+int gpmc_seq_end(gpmc_seq* seq);
+int gpmc_seq_launch(gpmc_seq* seq, gpmc_stream_t stream);
+int gpmc_seq_retire(gpmc_seq* seq);
+/* re-arm that trapezoidal block for the next factorisation: rows (np_ x np_, ld) <- diagonal *diag_dev (device scalar),
+ * zero right of it; the strict lower part -- never written by gpmc_potrf_tri -- is left alone (half the bytes of a memset,
+ * and no host value in the launch: it can be part of a recorded sequence).  np_ a multiple of 64. */
+int gpmc_reset_tri_f64(double* rows, int np_, int ld, const double* diag_dev, gpmc_stream_t stream);
+int gpmc_reset_tri_f32(float* rows, int np_, int ld, const float* diag_dev, gpmc_stream_t stream);
 int gpmc_potrf_tri_f64(double* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch,
                        gpmc_stream_t stream);
 int gpmc_potrf_tri_f32(float* W, int mp, int np_, int ldw, int ntri, int* info_dev, void* scratch,

@@ -11,5 +11,5 @@ X, g, pts = bench.synth_inputs(n, 2)
 ws = sds.SDSWorkspace(X)
 f = torch.zeros(n, dtype=torch.float64, device='cuda'); gd = torch.as_tensor(g).cuda()
 for j, h in enumerate(pts):
-    ws._set_hyp(h); ws._factor_A(gd, 0.0); ws._make_R(gd); ws._chol_R(f, False, 0.0)
+    ws.f_in.copy_(f); ws.g_in.copy_(gd); ws._set_hyp(h); ws._factor_A(0.0); ws._make_R(); ws._chol_R(0.0)
     print('point %2d: first attempt info = %d of %d' % (j, int(ws.infoR.item()), n), flush=True)

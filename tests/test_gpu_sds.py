@@ -385,6 +385,31 @@ def test_full_size_sds_proposal_properties(gp):
     assert abs(G - ref) <= 1e-8 * abs(ref)
 
 
+@pytest.mark.parametrize('n', [1500, 7300])
+def test_recorded_proposal_sequence_matches_eager(gp, n):
+    """``SDSWorkspace.proposal`` -- the sampler's loop body (sliceSample.py:136-147) as ONE recorded launch sequence with
+    one synchronisation -- against the eager route it replaced (``aux_var_model`` + ``propose_f`` on a second workspace):
+    G' and f' bit for bit over six proposals (the first eager, the second recording, the rest replays), at a one-launch
+    size and at a two-stream size (7300: the look-ahead's second stream joins the capture through its event edges)."""
+    X, g0 = _bench_like(n, 2)
+    f = torch.as_tensor(np.random.RandomState(2).standard_normal(n)).cuda()
+    g = torch.as_tensor(g0).cuda()
+    pts = [[1.0, 10.0, 1.2], [1.3, 9.0, 1.1], [0.8, 12.0, 1.5], [2.0, 7.0, 0.9], [1.1, 10.5, 1.25], [0.9, 11.0, 1.0]]
+    ws, ws2 = gp['sds'].SDSWorkspace(X), gp['sds'].SDSWorkspace(X)
+    ws.aux_var_model(f, pts[0], g, need_eta=True)
+    ita = ws.eta.clone()
+    ws.begin(f, g, ita)
+    got = [ws.proposal(p) for p in pts]
+    assert ws._seq is not None
+    for p, (G, fp) in zip(pts, got):
+        Gr = ws2.aux_var_model(f, p, g, need_eta=False)
+        fr = ws2.propose_f(ita).cpu().numpy()
+        assert G == Gr, (p, G, Gr)
+        assert np.array_equal(fp, fr), (p, float(np.abs(fp - fr).max()))
+    ref = sds_ref.gp_log_marginal(X, g0, pts[2])
+    assert abs(got[2][0] - ref) <= 1e-8 * abs(ref)
+
+
 def test_sds_forms_agree_at_size(gp):
     """N = 4096 (big tiles, trapezoidal riding rows, triangular SYRK): the two algebraic forms of the SDS block give the
     same L bit for bit (the riding rows do not feed back), the same log-marginal, m to 1e-9 and R + 1e-11 I to 1e-8 in
