@@ -130,6 +130,35 @@ def pmc_traffic(n, kernel_prefix='gpmc::gemm4_nt_kernel'):
     return (num / den if den else None), os.path.relpath(files[-1], ROOT)
 
 
+def sq_counters(n, kernel_prefix):
+    """MFMA-pipe busy %, issue-stall %, parked %, LDS bank-conflict % and L2 hit % of a kernel from the committed
+    rocprofv3 SQ / GRBM / TCC passes over this same command (profiles/r*_bench_n<N>_sq.json, written by
+    scripts/counter_summary.py from scripts/sq_counters.sh), dispatch-weighted over the kernel's instantiations."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_n%d_sq.json' % n)))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        doc = json.load(fh)
+    acc, wsum = {}, 0.0
+    for name, e in doc.get('kernels', {}).items():
+        if name.startswith(kernel_prefix):
+            w = float(e.get('dispatches', 0))
+            # weight by time: dispatches x resident cycles
+            w *= float(e.get('derived', {}).get('kernel_cycles', 1.0))
+            wsum += w
+            for k, v in e.get('derived', {}).items():
+                if k.endswith('_pct'):
+                    acc[k] = acc.get(k, 0.0) + w * v
+    if not wsum:
+        return None
+    out = {k: v / wsum for k, v in acc.items()}
+    out['source'] = os.path.relpath(files[-1], ROOT)
+    out['note'] = ('time-weighted over the kernel\'s launches; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), '
+                   'wait_inst = issue stalls / wave cycles, wait_any = parked at s_waitcnt / barriers / sleeps')
+    return out
+
+
 # ------------------------------------------------------------------------------------------ CPU baselines
 def blas_info():
     try:
@@ -285,11 +314,20 @@ def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
         if r[3] != 0:
             raise SystemExit('%s: factorisation reported info=%d' % (name, r[3]))
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    npipe = min(steps, RING)
+    for i in range(npipe):                                              # back to back (never the quoted rate)
+        plan.eval_async(pts[i % len(pts)], i)
+    plan.drain()
+    torch.cuda.synchronize()
+    ms_pipe = 1e3 * (time.perf_counter() - t0) / npipe
     plan.close()
     peak = 157.3 if dtype_name == 'f32' else FP64_MATRIX_PEAK_TF
     tf = n ** 3 / 3.0 / (ms * 1e-3) / 1e12
     out = {'workload': '%s, N=%d, d=%d, %s' % ('RBF' if kernel == 'rbf' else 'ARD Matern-5/2', n, d, dtype_name),
-           'ms_per_eval': ms, 'evals_per_s': 1e3 / ms, 'steps': steps, 'tflops': tf, 'peak_tflops': peak, 'frac_of_peak': tf / peak}
+           'ms_per_eval': ms, 'evals_per_s': 1e3 / ms, 'steps': steps, 'tflops': tf, 'peak_tflops': peak, 'frac_of_peak': tf / peak,
+           'enqueue': 'sync-each (result read before the next evaluation)', 'ms_per_eval_pipelined': ms_pipe}
     if dtype_name == 'f32':
         p64 = core.LogMarginalPlan(X, g, kernel, dtype=torch.float64, settle=False)
         v64 = [p64(p) for p in pts]
@@ -550,13 +588,14 @@ def main():
                     'avg_launch_us': 1e3 * ms / max(launches, 1), 'algorithmic_flops_per_launch': flops / max(launches, 1),
                     'kernel_ms_per_step': ms / max(a.steps, 1), 'note': note,
                     'traffic': tr, 'traffic_unit': 'HBM-side bytes per launch (PMC)', 'traffic_source': src,
-                    'traffic_measured_in_run': False}
+                    'traffic_measured_in_run': False,
+                    'counters': sq_counters(a.n, prefix) if (a.d == 2 and not stub) else None}
         r_gemm = roof('gpmc::gemm4_nt_kernel (trailing SYRK update of the blocked Cholesky)', 'gpmc::gemm4_nt_kernel',
-                      k_ms, k_launches, k_flops, 'K = 384 rank updates (outer block of the look-ahead at this size) on v_mfma_f64_4x4x4, 128x128 tiles')
+                      k_ms, k_launches, k_flops, 'K = %d rank updates (outer block of the look-ahead at this size) on v_mfma_f64_4x4x4, 128x128 tiles' % (512 if a.n > 8064 else 384))
         r_dag = roof('gpmc::tail_kernel (tile-DAG factorisation: look-ahead panels and the last <= 6144 columns)',
                      'gpmc::tail_kernel', d_ms, d_launches, d_flops,
                      'one launch per panel / tail; bulk on v_mfma_f64_16x16x4 from 64x64 LDS tiles (operands prefetched '
-                     'in the tail launch), critical path = the pivot chain (17-19 us per 64 columns) on '
+                     'in the tail launch), critical path = the pivot chain (17 us per 64 columns) on '
                      'v_mfma_f64_4x4x4; panel launches overlap the GEMM on a second stream, so '
                      'kernel_ms_per_step of the two kernels add up to more than the step')
         roofline, roofline_other = (r_dag, r_gemm) if d_ms >= k_ms else (r_gemm, r_dag)

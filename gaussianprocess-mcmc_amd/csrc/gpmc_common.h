@@ -65,6 +65,9 @@ struct Options {
     int tail_prefetch_t = 72; // whole / tail tile-DAG launches of at least this many tile columns prefetch the next column's
                               // operands under the MFMA phase (0 = never; needs tail_acc16)
     int dag_prefetch = 0;     // ... look-ahead panel launches too (8192: +-0, 9216: -0.9 %, 12288: +2 %)
+    int tail_skip = 3;        // what a tile-DAG launch leaves out when the caller has said how many riding rows are in use
+                              // (gpmc_potrf_rhs): bit 0 the unused 64-row half of the riding block, bit 1 the MFMAs of waves
+                              // whose 16 rows of the used half hold no right-hand side
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);
                               // 0 = auto by the launch's bulk-to-chain ratio (potrf.hip, alone_workers: 256 - T, 256 or 480)
@@ -168,7 +171,8 @@ int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, in
            int rows_out, int cols_out, int ldk, int flags, hipStream_t s, KbuildExtras<T> ex = KbuildExtras<T>());
 struct Sched;
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0, Sched* sc = nullptr);
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri = 0, Sched* sc = nullptr,
+          int rhs_rows = -1);
 // host_base / slot_dev (both or neither): the four results also go straight to pinned host memory, 4 doubles at
 // host_base + 4 * (int)*slot_dev, so that no copy has to follow the reduction
 template <typename T>

@@ -85,7 +85,7 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
                        GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s, ex);
     if (rc) return rc;
     p->sched.info_cleared = true;
-    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched);
+    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched, 1);      // one riding row: g
     p->sched.info_cleared = false;
     if (rc) return rc;
     return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s, p->host_res_dev, hyp + (2 + PLAN_MAXD));
@@ -183,6 +183,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "tail_skip")) g_opt.tail_skip = value & 3;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
     else if (!strcmp(name, "tail_prefetch_t")) g_opt.tail_prefetch_t = value;
     else if (!strcmp(name, "dag_prefetch")) g_opt.dag_prefetch = value ? 1 : 0;
@@ -233,6 +234,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "tail_skip")) return g_opt.tail_skip;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
     if (!strcmp(name, "tail_prefetch_t")) return g_opt.tail_prefetch_t;
     if (!strcmp(name, "dag_prefetch")) return g_opt.dag_prefetch;
@@ -337,6 +339,12 @@ int gpmc_reset_tri_f64(double* R, int np_, int ld, const double* diag_dev, gpmc_
 }
 int gpmc_reset_tri_f32(float* R, int np_, int ld, const float* diag_dev, gpmc_stream_t stream) {
     return reset_tri<float>(R, np_, ld, diag_dev, S_(stream));
+}
+int gpmc_potrf_rhs_f64(double* W, int mp, int np_, int ldw, int ntri, int rhs_rows, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<double>(W, mp, np_, ldw, info_dev, scratch, S_(stream), ntri, nullptr, rhs_rows);
+}
+int gpmc_potrf_rhs_f32(float* W, int mp, int np_, int ldw, int ntri, int rhs_rows, int* info_dev, void* scratch, gpmc_stream_t stream) {
+    return potrf<float>(W, mp, np_, ldw, info_dev, scratch, S_(stream), ntri, nullptr, rhs_rows);
 }
 int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int n, int np_, int ldc, gpmc_stream_t stream) {
     return syrk_tri<double>(P, ldp, diag_add, C, n, np_, ldc, S_(stream));

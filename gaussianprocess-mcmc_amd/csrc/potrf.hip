@@ -612,7 +612,7 @@ static int factor_panel(T* W, int ld, int k0, int nbk, int mp, int* info_dev, T*
 }
 
 template <typename T>
-int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri, Sched* sc) {
+int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStream_t s, int ntri, Sched* sc, int rhs_rows) {
     GPMC_ARG(W != nullptr, 1);
     GPMC_ARG(np_ > 0 && np_ % GPMC_PAD == 0, 3);
     GPMC_ARG(mp >= np_ && mp % GPMC_PAD == 0, 2);
@@ -622,6 +622,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     GPMC_ARG(reinterpret_cast<uintptr_t>(W) % 16 == 0, 1);
     GPMC_ARG(ntri >= 0 && ntri % GPMC_PAD == 0 && ntri <= mp - np_, 8);
     GPMC_ARG(sc == nullptr || sc->main == s, 9);
+    GPMC_ARG(rhs_rows < 0 || rhs_rows <= mp - np_ - ntri, 10);
+    // rhs_rows = meaningful rows of the riding block right below the matrix (-1: unknown, all of it).  The block is padded
+    // to 128 rows; with at most 64 of them in use -- the log-marginal's g, the sampler's f - m: ONE row -- its second
+    // 64-row half is zero before and after, and the tile-DAG launches leave it alone (2 of the ~90 tile rows of an
+    // N = 8192 tail launch are riding rows: 2.4 of its 100 Gflop went into that half)
+    const int dead_row64 = ((g_opt.tail_skip & 1) && rhs_rows >= 0 && rhs_rows <= NB_IN && mp - np_ - ntri >= 2 * NB_IN) ? np_ / NB_IN + 1 : -1;
+    // ... and of the first half only the waves (16 rows each) that hold a right-hand side issue MFMAs
+    const int ride_waves = ((g_opt.tail_skip & 2) && rhs_rows >= 1 && rhs_rows <= NB_IN && mp - np_ - ntri >= NB_IN) ? (rhs_rows + 15) / 16 : 4;
     // The last ntri riding rows are upper-trapezoidal on entry (riding row mp - ntri + i is zero left of column i, e.g.
     // a scaled identity, which leaves s L^-T behind).  Row i then stays zero in every column < i, so while the panel
     // ending at column kend is factored or applied only the first kend of those rows can hold anything: the launches
@@ -726,7 +734,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
 #define GPMC_TAIL_LAUNCH(A16, PRE)                                                                                       \
         hipLaunchKernelGGL((tail_kernel<T, A16, PRE>), dim3(grid), dim3(256), sizeof(TailShared), st, W, ldw, k0, Tt, Rt, Hh, \
                            (mp_rows - ntri - k0) / NB_IN, sync, info_dev, g_tail_dbg, st == s ? 0 : g_opt.dag_wprio,          \
-                           (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags)
+                           (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags,                                            \
+                           (dead_row64 >= k0 / NB_IN && dead_row64 < k0 / NB_IN + Rt) ? dead_row64 - k0 / NB_IN : -1,       \
+                           (ride_waves < 4 && np_ / NB_IN < k0 / NB_IN + Rt) ? (np_ - k0) / NB_IN : -1, ride_waves)
         // variants (tail.h): the 4x4x4 accumulation (cross-checks only); the 16x16x4 accumulation; the same with the next
         // column's operands prefetched -- for launches whose time is their bulk, not their pivot chain
         const bool pre = g_opt.tail_acc16 && sizeof(T) == 8 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)
@@ -1131,8 +1141,8 @@ int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStrea
     return 0;
 }
 
-template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int, Sched*);
-template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int, Sched*);
+template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int, Sched*, int);
+template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int, Sched*, int);
 template int syrk_tri<double>(const double*, int, double, double*, int, int, int, hipStream_t);
 template int syrk_tri<float>(const float*, int, float, float*, int, int, int, hipStream_t);
 template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);

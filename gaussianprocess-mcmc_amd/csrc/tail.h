@@ -237,7 +237,7 @@ template <typename TS, int ACC16, bool PRE>
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
-            const unsigned* __restrict__ gflag, int gmt, int park_on) {
+            const unsigned* __restrict__ gflag, int gmt, int park_on, int dead, int ride_row, int ride_waves) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
@@ -258,7 +258,9 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // the launch's column col lies left of the block's first row index: it is never worked on, never published, and
     // its updates of other tiles are skipped.  tri0 = R: no such rows.
     const int gb = k0 / 64;
-    auto zero_tile = [&](int ti_, int col) { return ti_ >= tri0 && col + gb < ti_ - tri0; };
+    // dead >= 0: that block row (the unused half of a 128-row riding block that holds one right-hand side) is zero in
+    // every column for the same reason.
+    auto zero_tile = [&](int ti_, int col) { return ti_ == dead || (ti_ >= tri0 && col + gb < ti_ - tri0); };
     // Roles.  Block l < T is the pair of column l (owns (l,l) and, for l >= 1, (l,l-1)), the others are workers -- but a
     // pair role belongs to whoever CLAIMS it first (claim[l], one word per column), and blocks T .. 2T+15 look, ~8 us
     // after they start, for roles nobody has claimed and take one over; the late owner then finds its role gone and is
@@ -346,6 +348,10 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             if (!alive) break;
         }
     }
+    // The first riding block row holds ride_waves x 16 rows of right-hand sides at most (ONE row for the log-marginal and
+    // for the sampler): a wave whose 16 rows of such a tile are zero keeps them zero without an MFMA (its accumulators start
+    // and stay at zero; it still stages, waits and stores with the others).
+    const bool idle_wave = !pair && ti == ride_row && w >= ride_waves;
     // ---------------- tiles into registers
     double D[4][4];     // (tl,tl), slab layout: lane (i, c) of D[m][h] = element [4 (w + 4 m) + i][16 h + c]
     // off-diagonal tile, transposed: lane (i, c) of XG(g) = element [16 w + c][4 g + i]; the four slabs g = 4b .. 4b+3 are
@@ -427,6 +433,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             // back to back), but a mix loses to all-16x16x4 with and without prefetch (N = 8192: 2 blocks 4.47 ms,
             // 3 blocks 4.50, 4 blocks 4.35; 7168: 3.28 / 3.26 / 3.07): fewer instructions win.
             // Both forms produce the same bits (same k order inside an instruction).
+            if (idle_wave) continue;
             if constexpr (ACC16 > 0) {
                 d2_t aB[ACC16];
 #pragma unroll
@@ -591,6 +598,7 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
+                if (idle_wave) break;
                 const double av = sh.Linv[p][ia][i];
                 const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, XG(p), 0.0, 0, 0, 0);
                 XG(p) = Y;

@@ -59,6 +59,7 @@ def _sig(lib):
         'gpmc_pack_rows_f64': ([P, I, I, I, P, I, I, I, P], I), 'gpmc_pack_rows_f32': ([P, I, I, I, P, I, I, I, P], I),
         'gpmc_unpack_lower_f64': ([P, I, I, P, I, I, P], I), 'gpmc_unpack_lower_f32': ([P, I, I, P, I, I, P], I),
         'gpmc_unpack_rows_f64': ([P, I, I, P, I, I, I, P], I), 'gpmc_unpack_rows_f32': ([P, I, I, P, I, I, I, P], I),
+        'gpmc_potrf_rhs_f64': ([P, I, I, I, I, I, P, P, P], I), 'gpmc_potrf_rhs_f32': ([P, I, I, I, I, I, P, P, P], I),
         'gpmc_potrf_tri_f64': ([P, I, I, I, I, P, P, P], I),
         'gpmc_potrf_tri_f32': ([P, I, I, I, I, P, P, P], I),
         'gpmc_reset_tri_f64': ([P, I, I, P, P], I), 'gpmc_reset_tri_f32': ([P, I, I, P, P], I),

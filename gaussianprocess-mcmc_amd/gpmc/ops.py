@@ -79,15 +79,16 @@ def kbuild(kernel, X, kparams_dev, out, n_rows, n_cols, flags, Z=None):
     return out
 
 
-def potrf(W, mp, np_, info, scratch):
-    check(_fn('potrf', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), info.data_ptr(), scratch.data_ptr(),
-                                stream_ptr()), 'gpmc_potrf')
+def potrf(W, mp, np_, info, scratch, rhs_rows=-1):
+    """``rhs_rows``: rows in use of the riding block right below the matrix (-1: unknown), see gpmc_potrf_rhs"""
+    check(_fn('potrf_rhs', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), 0, rhs_rows, info.data_ptr(), scratch.data_ptr(),
+                                    stream_ptr()), 'gpmc_potrf')
 
 
-def potrf_tri(W, mp, np_, ntri, info, scratch):
+def potrf_tri(W, mp, np_, ntri, info, scratch, rhs_rows=-1):
     """gpmc_potrf_tri: the last ``ntri`` riding rows are upper-trapezoidal on entry (e.g. s*I -> s*L^-T)"""
-    check(_fn('potrf_tri', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), ntri, info.data_ptr(), scratch.data_ptr(),
-                                    stream_ptr()), 'gpmc_potrf_tri')
+    check(_fn('potrf_rhs', W.dtype)(W.data_ptr(), mp, np_, W.stride(0), ntri, rhs_rows, info.data_ptr(),
+                                    scratch.data_ptr(), stream_ptr()), 'gpmc_potrf_tri')
 
 
 def reset_tri(rows, np_, diag_dev):

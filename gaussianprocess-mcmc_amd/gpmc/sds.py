@@ -25,6 +25,8 @@ Form ``'syrk'`` is the first implementation (8 N^3 / 3): K itself rides on the f
 R = K - V^T V is a full SYRK (N^3); kept for cross-checks.  Both follow the reference's seeded chains decision for
 decision (tests/test_gpu_sds.py); the reference itself spends ~11.3 N^3 flops here (dense S, LU solves, two inverses).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -82,6 +84,7 @@ class SDSWorkspace(object):
         self._seq = None
         self._seq_stream = None
         self._proposals = 0
+        self._last_stream = None   # the stream the last sequence went to, when it is not the current one
         self._dirty = False        # a failed factorisation of K + S has run: its riding rows may hold NaN anywhere
 
     # ------------------------------------------------------------------ pieces
@@ -114,7 +117,7 @@ class SDSWorkspace(object):
             ops.kbuild(self.kernel, self.X, self.kp0, rows, np_, np_, ops.KB_FULL)
         ops.veccopy(self.WA[self.g_row], self.g_in, n)           # (a kernel, not a copy node: see _record)
         if self.form == 'inv':
-            ops.potrf_tri(self.WA, self.mpA, np_, np_, self.infoA, self.scratch)
+            ops.potrf_tri(self.WA, self.mpA, np_, np_, self.infoA, self.scratch, rhs_rows=1)      # one row in the g block
         else:
             ops.potrf(self.WA, self.mpA, np_, self.infoA, self.scratch)
         ops.logdet_quad(self.WA, n, self.WA[self.g_row], self.infoA, self.out)
@@ -153,7 +156,7 @@ class SDSWorkspace(object):
         n, np_ = self.n, self.np_
         self.WR.diagonal()[:n].add_(R_JITTER + jitter)
         torch.sub(self.f_in, self.m, out=self.WR[np_, :n])
-        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratchR)
+        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratchR, rhs_rows=1)                 # f - m
 
     def _results(self):
         """[G, logdet, quad, infoA], infoR and f' -> pinned host memory, written by a kernel (asynchronous; read after a
@@ -161,7 +164,8 @@ class SDSWorkspace(object):
         ops.publish_host(self.out, self.infoR, self.prop_f, self.n, self.res_host)
 
     def _read(self):
-        torch.cuda.current_stream().synchronize()                # the one sync of the happy path
+        (self._last_stream or torch.cuda.current_stream()).synchronize()       # the one sync of the happy path
+        self._last_stream = None
         r = self.res_host
         return float(r[0]), _lib.check_info(r[3]), _lib.check_info(r[4])
 
@@ -286,6 +290,8 @@ class SDSWorkspace(object):
         with the iteration's g, prop_f, propG).  The first proposal of a workspace launches eagerly, the second records
         the sequence, later ones replay it: ONE stream synchronisation per proposal.  If a factorisation fails the
         jitter schedules run eagerly, exactly as in ``aux_var_model``."""
+        if os.environ.get('GPMC_SDS_RECORD') == '0':     # development: eager launches
+            record = False
         self._set_hyp(hyp)
         self._retried = False
         self._sA = self.Sii              # the recorded sequence is the jitter-free path (the eager one sets it itself)
@@ -295,7 +301,13 @@ class SDSWorkspace(object):
             self._record()
         if self._seq is not None and record:
             self._clean()
-            _lib.check(_lib.lib().gpmc_seq_launch(self._seq, ops.stream_ptr()), 'gpmc_seq_launch')
+            # replayed on the stream it was recorded on, behind whatever the current stream holds (the staged parameters,
+            # begin()'s copies): launched into the legacy NULL stream -- torch's default -- every node of the exec
+            # synchronises with it, and a proposal at N = 1024 took 1.8 instead of 0.8 ms
+            side = self._seq_stream
+            side.wait_stream(torch.cuda.current_stream())
+            _lib.check(_lib.lib().gpmc_seq_launch(self._seq, side.cuda_stream), 'gpmc_seq_launch')
+            self._last_stream = side
         else:
             self._sequence()
         self._proposals += 1

@@ -82,6 +82,14 @@ int gpmc_potrf_f32(float* W, int mp, int np_, int ldw, int* info_dev, void* scra
  * returns s L^-T, i.e. the explicit inverse factor, for N^3/3 flops instead of the N^3 of a dense right-hand side:
  * those rows stay zero left of their diagonal, so every launch stops at the last row that can hold anything.
  * This is how the SDS block gets R = S - S (K+S)^-1 S (== K - V^T V, sliceSample.py:197-198) -- see gpmc_syrk_tri. */
+/* gpmc_potrf / gpmc_potrf_tri with one more fact from the caller: only the first rhs_rows rows of the riding block right
+ * below the matrix (rows np_ .. np_ + 127 of a block padded to GPMC_PAD) are in use, the rest of that block is zero.  With
+ * rhs_rows <= 64 the one-launch factorisation skips the block's second 64-row half (it stays zero).  ntri as in
+ * gpmc_potrf_tri (0: none); rhs_rows = -1: unknown (= gpmc_potrf / gpmc_potrf_tri). */
+int gpmc_potrf_rhs_f64(double* W, int mp, int np_, int ldw, int ntri, int rhs_rows, int* info_dev, void* scratch,
+                       gpmc_stream_t stream);
+int gpmc_potrf_rhs_f32(float* W, int mp, int np_, int ldw, int ntri, int rhs_rows, int* info_dev, void* scratch,
+                       gpmc_stream_t stream);
 /* small companions of the SDS proposal sequence (gpmc/sds.py): a vector copy as a kernel, and the proposal's results --
  * out4 (gpmc_logdet_quad), the second factorisation's info word and a vector (f') -- written straight into pinned,
  * device-mapped host memory: host[0..3] = out4, host[4] = *info2, host[8 .. 8 + n) = vec (as doubles). */
@@ -253,7 +261,7 @@ int gpmc_profile_read(double* out6);
  * "la_min_m", "la_nb128_m", "la_depth", "la_order", "panel_pair", "panel_prio", "panel_lds_pad", "use_graph",
  * "small_tile_m", "f32_nb", "gemm_lds_pad"; the tile-DAG schedule (round 2) "tail_m" / "tail_whole_m" (columns the
  * one-launch factorisation takes as a tail / whole; "_f32" variants for float storage), "tail_workers", "dag_workers",
- * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "tail_park", "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
+ * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "tail_park", "tail_skip" (bit 0: skip the unused half of a riding block, bit 1: its idle waves; gpmc_potrf_rhs), "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
  * "tail_acc16" (1: off-diagonal accumulation on v_mfma_f64_16x16x4; 0: the 4x4x4 form, same bits), "tail_prefetch_t" (tail /
  * whole launches of at least this many tile columns prefetch the next column's operands; 0 = never), "dag_prefetch",
  * "replay_form", "graveyard_max", "shared_card" (1: other processes use this card too -- see INTEGRATION.md section 4); alternative kernels

@@ -18,3 +18,5 @@ f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_st
 # keep the merge small: drop the raw per-dispatch traces
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 cat $OUT/line_under_rocprof.json | cut -c1-400
+# SQ / GRBM / TCC counter passes (MFMA busy, stalls, LDS conflicts, L2 hit rate) over the same command
+bash scripts/sq_counters.sh $R > $OUT/sq.log 2>&1; cp gpurun_out/sq_$R/summary.json $OUT/sq_summary.json; cp gpurun_out/sq_$R/summary.txt $OUT/sq_summary.txt
