@@ -429,9 +429,10 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             // for cross-checks): A[m][k] = L_{xl,col}[16 b + m][k] from lane (k = i, m = c), one accumulator per 16 tile
             // columns -- one LDS operand read per 4096 flops where the 4x4x4 form needs one per 1024 (it replicates every
             // A value over four lanes, and the LDS charges for the replicas: 1088 LDS cycles against 1024 MFMA cycles
-            // per CU and k8 step with two workgroups per CU).  The 4x4x4 instruction has the higher rate (74 vs 49 TF/s
-            // back to back), but a mix loses to all-16x16x4 with and without prefetch (N = 8192: 2 blocks 4.47 ms,
-            // 3 blocks 4.50, 4 blocks 4.35; 7168: 3.28 / 3.26 / 3.07): fewer instructions win.
+            // per CU and k8 step with two workgroups per CU).  One wave issuing back to back gets 74 TF/s out of the 4x4x4
+            // shape and 49 out of this one, but both hold the pipe for 32 flop per cycle and two waves per SIMD fill each
+            // other's issue gaps (PMC, round 3); a mix loses to all-16x16x4 with and without prefetch (N = 8192: 2 blocks
+            // 4.47 ms, 3 blocks 4.50, 4 blocks 4.35; 7168: 3.28 / 3.26 / 3.07): fewer instructions win.
             // Both forms produce the same bits (same k order inside an instruction).
             if (idle_wave) continue;
             if constexpr (ACC16 > 0) {
