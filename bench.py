@@ -476,6 +476,7 @@ def main():
         torch.cuda.synchronize()
         dt_instr = time.perf_counter() - t1
         (k_ms, k_launches, k_flops), (d_ms, d_launches, d_flops) = _lib.profile_read()
+        gpmc.set_option('use_graph', 1)             # (everything after this pass records and replays again)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or (world == 1 and dev is not None)) else 'cpu')
     if grouped:

@@ -68,6 +68,12 @@ struct Options {
     int tail_skip = 3;        // what a tile-DAG launch leaves out when the caller has said how many riding rows are in use
                               // (gpmc_potrf_rhs): bit 0 the unused 64-row half of the riding block, bit 1 the MFMAs of waves
                               // whose 16 rows of the used half hold no right-hand side
+    int tail_xcd = 0;         // 1: tile-DAG worker tickets in eight queues by column (mod 8), each served first by the workgroups of
+                              // one XCD, so that an XCD's L2 holds one column's A operands instead of five columns' -- in launches
+                              // that have the chip to themselves, never when other processes share the card.  Measured (same
+                              // process, ms/eval off / on): N = 5120 1.548 / 1.517, 6144 2.130 / 2.093, 7168 3.022 / 3.010,
+                              // 8192 4.270 / 4.269 (its tail launch carries 8 history columns), <= 4096 +-0; in the look-ahead
+                              // panels (8 columns, 32 workers per queue) beside the GEMM +0.8 %.  Off: nothing for the headline.
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);
                               // 0 = auto by the launch's bulk-to-chain ratio (potrf.hip, alone_workers: 256 - T, 256 or 480)

@@ -183,6 +183,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "tail_xcd")) g_opt.tail_xcd = value ? 1 : 0;
     else if (!strcmp(name, "tail_skip")) g_opt.tail_skip = value & 3;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
     else if (!strcmp(name, "tail_prefetch_t")) g_opt.tail_prefetch_t = value;
@@ -234,6 +235,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "tail_xcd")) return g_opt.tail_xcd;
     if (!strcmp(name, "tail_skip")) return g_opt.tail_skip;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
     if (!strcmp(name, "tail_prefetch_t")) return g_opt.tail_prefetch_t;

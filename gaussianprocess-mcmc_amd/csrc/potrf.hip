@@ -736,7 +736,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                            (mp_rows - ntri - k0) / NB_IN, sync, info_dev, g_tail_dbg, st == s ? 0 : g_opt.dag_wprio,          \
                            (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags,                                            \
                            (dead_row64 >= k0 / NB_IN && dead_row64 < k0 / NB_IN + Rt) ? dead_row64 - k0 / NB_IN : -1,       \
-                           (ride_waves < 4 && np_ / NB_IN < k0 / NB_IN + Rt) ? (np_ - k0) / NB_IN : -1, ride_waves)
+                           (ride_waves < 4 && np_ / NB_IN < k0 / NB_IN + Rt) ? (np_ - k0) / NB_IN : -1, ride_waves,          \
+                           (g_opt.tail_xcd && !g_opt.shared_card && st == s && workers >= 256) ? 8 : 1)
         // variants (tail.h): the 4x4x4 accumulation (cross-checks only); the 16x16x4 accumulation; the same with the next
         // column's operands prefetched -- for launches whose time is their bulk, not their pivot chain
         const bool pre = g_opt.tail_acc16 && sizeof(T) == 8 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)

@@ -50,11 +50,12 @@
 namespace gpmc {
 
 constexpr int TAIL_MAXT = 128;                  // block columns of one launch
-// sync words of one launch: [0] abort word, [1] ticket counter, then flag[col][row], row stride R
+// sync words of one launch: a header (TAIL_HDR: abort word, ticket counters), then flag[col][row], row stride R
 // ... then busy[TAIL_CUS]: number of pairs inside their critical window on each CU (key = __smid()), see tail_kernel
 constexpr int TAIL_CUS = 1024;
 // ... then claim[TAIL_MAXT]: pair role l has been taken
-__host__ __device__ inline size_t tail_sync_words(int T, int R) { return 4 + (size_t)T * R + TAIL_CUS + TAIL_MAXT; }
+constexpr int TAIL_HDR = 16;                    // [0] abort word, [8 .. 15] ticket counters of the (up to) eight worker queues
+__host__ __device__ inline size_t tail_sync_words(int T, int R) { return TAIL_HDR + (size_t)T * R + TAIL_CUS + TAIL_MAXT; }
 constexpr size_t TAIL_SYNC_BYTES = 2u << 20;    // device scratch reserved for the sync words of ONE factorisation's launches
 constexpr unsigned TAIL_SPIN_LIMIT = 1u << 20;  // default number of polls before giving up (~1 s)
 constexpr int GPMC_TAIL_TIMEOUT = -1001;        // *info when the kernel gave up waiting and no cause was recorded
@@ -237,19 +238,19 @@ template <typename TS, int ACC16, bool PRE>
 __global__ void __launch_bounds__(256, 2)
 tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, unsigned* __restrict__ sync,
             int* __restrict__ info, unsigned long long* __restrict__ dbg, int wprio, unsigned spin_limit,
-            const unsigned* __restrict__ gflag, int gmt, int park_on, int dead, int ride_row, int ride_waves) {
+            const unsigned* __restrict__ gflag, int gmt, int park_on, int dead, int ride_row, int ride_waves, int nq) {
     extern __shared__ __attribute__((aligned(16))) char tail_smem[];
     TailShared& sh = *reinterpret_cast<TailShared*>(tail_smem);
     double (*Lout)[MP_LD] = sh.Ld;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int i = lane >> 4, c = lane & 15, ia = lane & 3;
     unsigned* const abortw = sync;
-    auto flag = [&](int col, int row) { return sync + 4 + col * R + row; };
+    auto flag = [&](int col, int row) { return sync + TAIL_HDR + col * R + row; };
     // A worker that shares its CU with a pair inside its critical window (from the wait for F(l-1) to the publication of
     // F(l)) steps aside for that window: its MFMA stream slows the pair's factor wave (FP64 VALU, one wave) and the
     // chain with it.  busy[cu] counts such pairs; a worker looks at its CU's word once per column (the load rides on
     // the column's operand loads) and, if set, sleeps after that column until the word clears (bounded).
-    unsigned* const busy = ((park_on & 1) ? sync + 4 + T * R + (__smid() & (TAIL_CUS - 1)) : nullptr);
+    unsigned* const busy = ((park_on & 1) ? sync + TAIL_HDR + T * R + (__smid() & (TAIL_CUS - 1)) : nullptr);
     TS* const W0 = W + (size_t)k0 * ld + k0;                      // tile (0,0)
     auto tile = [&](int ti, int tl) { return W0 + (size_t)(64 * ti) * ld + 64 * tl; };
 
@@ -271,8 +272,17 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     // as enough of its first blocks run ANYWHERE; with the chip to itself every block claims its own role within the
     // launch's first microsecond and nothing changes (handing the roles out purely by arrival put the pairs on
     // arbitrary CUs and cost 1-4 % at N = 8192).
-    unsigned* const ticketw = sync + 1;
-    unsigned* const claim = sync + 4 + T * R + TAIL_CUS;
+    // Worker tickets.  nq = 1: one queue, every off-diagonal tile in column-major order.  nq = 8 (a process that has the card
+    // to itself): queue q holds the columns l = q (mod 8), column-major, and a worker draws from the queue of the XCD it
+    // runs on first -- the workgroups of an XCD then work on ONE column at a time, whose A operands (the tiles of block row
+    // l: up to 3 MB) stay in that XCD's 4 MB L2, instead of on the five or so columns in flight chip-wide -- and from the
+    // next queues once its own is empty.  Within a queue tickets are still drawn in column order by running workgroups, so a
+    // ticket only ever waits for pairs and for columns to its left, whose lowest unfinished one always has all its drawn
+    // tickets in running hands; every queue needs SOME running workgroup to serve it, which a launch dealt round-robin to
+    // eight XCDs has while the card is its own (with other processes on the card the host keeps nq = 1).
+    unsigned* const ticketw = sync + 8;
+    const int xcd = (nq > 1) ? (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & (unsigned)(nq - 1)) : 0;      // HW_REG_XCC_ID[3:0]
+    unsigned* const claim = sync + TAIL_HDR + T * R + TAIL_CUS;
     int role = (int)blockIdx.x;
     const bool by_index = (park_on & 8) != 0;     // (bit 3: no claims, measurements only -- option tail_roles_by_index)
     if (!by_index && role < 2 * T + 16) {
@@ -306,7 +316,6 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     if (pair) __builtin_amdgcn_s_setprio(3);      // the critical chain runs through these workgroups
     else if (wprio == 1) __builtin_amdgcn_s_setprio(1);
     else if (wprio == 2) __builtin_amdgcn_s_setprio(2);
-    const int ntiles = tail_tiles(T, R);
     bool alive = true;
     // A pair executes the 64 x 64 factor exactly once, inside its critical window, and on most CUs nobody has run that
     // code before (19 KB of the kernel): it would be fetched cold.  Pairs from column 2 on therefore run the body twice:
@@ -317,12 +326,25 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
     if (pair) {
         tl = ti = role;
     } else {
-        if (tid == 0) sh.tk = (int)__hip_atomic_fetch_add(ticketw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            int got = -1;
+            for (int k = 0; k < nq && got < 0; ++k) {          // own queue first, then the others' leftovers
+                const int qq = (xcd + k) & (nq - 1);
+                int nt = 0;
+                for (int l = qq; l < T; l += nq) nt += tail_col_tiles(l, T, R);
+                if ((int)tail_ld32(ticketw + qq) >= nt) continue;
+                const int t = (int)__hip_atomic_fetch_add(ticketw + qq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < nt) got = (t << 3) | qq;
+            }
+            sh.tk = got;
+        }
         __syncthreads();
         int q = sh.tk;
         __syncthreads();
-        if (q >= ntiles) break;
-        for (;; ++tl) {
+        if (q < 0) break;
+        tl = q & 7;
+        q >>= 3;
+        for (;; tl += nq) {
             const int n = tail_col_tiles(tl, T, R);
             if (q < n) break;
             q -= n;
