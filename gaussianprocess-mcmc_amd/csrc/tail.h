@@ -177,13 +177,16 @@ __device__ inline void tail_tile_in(double (*dst)[MP_LD], const TS* __restrict__
 }
 
 // LDS [row][col] -> W with write-through (sc1) stores; tail_drain() + barrier + the flag store follow
-template <typename TS>
+template <typename TS, bool SWZ = false>
 __device__ inline void tail_tile_out(TS* __restrict__ dst, int ld, const double (*src)[MP_LD], int tid) {
     const __amdgpu_buffer_rsrc_t r = tail_rsrc(dst);
     const int voff = (int)(((tid >> 5) * ld + (tid & 31) * 2) * sizeof(TS)), step = (int)(8 * ld * sizeof(TS));
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        TailRaw<TS>::store(r, voff + t * step, 0, *reinterpret_cast<const d2_t*>(&src[8 * t + (tid >> 5)][(tid & 31) * 2]));
+    for (int t = 0; t < 8; ++t) {
+        const int row = 8 * t + (tid >> 5);
+        const int ch = SWZ ? ((tid & 31) ^ tail_swz(row)) : (tid & 31);
+        TailRaw<TS>::store(r, voff + t * step, 0, *reinterpret_cast<const d2_t*>(&src[row][ch * 2]));
+    }
 }
 __device__ inline void tail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -619,36 +622,59 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
                 V[3][0] = i30; V[3][1] = i31; V[3][2] = i32; V[3][3] = i33;
             }
             __syncthreads();
+            // Step p multiplies slab p by its 4 x 4 inverse block and takes the result out of the 15 - p slabs below it: 136
+            // MFMAs with an LDS operand each.  Left to hipcc every MFMA waits for a read issued one or two instructions
+            // earlier (60 s_waitcnt lgkmcnt in the 136: 42 cycles per MFMA, 5.7 K cycles on the pivot chain); here the
+            // multipliers of step p + 1 are read while step p's MFMAs run (the empty asm pins that order).
+            double avn = sh.Linv[0][ia][i];
+            double aln[15];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) aln[g - 1] = Lout[4 * g + ia][i];
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 if (idle_wave) break;
-                const double av = sh.Linv[p][ia][i];
+                const double av = avn;
+                double alc[15];
+#pragma unroll
+                for (int g = p + 1; g < 16; ++g) alc[g - p - 1] = aln[g - p - 1];
+                if (p < 15) {
+                    avn = sh.Linv[p + 1][ia][i];
+#pragma unroll
+                    for (int g = p + 2; g < 16; ++g) aln[g - p - 2] = Lout[4 * g + ia][4 * (p + 1) + i];
+                }
+                asm volatile("" ::: "memory");
                 const double Y = __builtin_amdgcn_mfma_f64_4x4x4f64(av, XG(p), 0.0, 0, 0, 0);
                 XG(p) = Y;
                 const double Yn = -Y;          // one sign flip per step instead of one per multiplier
 #pragma unroll
-                for (int g = p + 1; g < 16; ++g) {
-                    const double al = Lout[4 * g + ia][4 * p + i];
-                    XG(g) = __builtin_amdgcn_mfma_f64_4x4x4f64(al, Yn, XG(g), 0, 0, 0);
-                }
+                for (int g = p + 1; g < 16; ++g)
+                    XG(g) = __builtin_amdgcn_mfma_f64_4x4x4f64(alc[g - p - 1], Yn, XG(g), 0, 0, 0);
+                asm volatile("" ::: "memory");
             }
             TAIL_STAMP(4);
+            // the tile leaves the registers transposed: lane (i, c) holds column 4 g + i of row 16 w + c.  Staged with the
+            // operand tiles' chunk swizzle (tail_swz): with plain rows the sixteen rows c of a store land on four banks
+            // (2.1 K cycles of 4-way conflicts on the chain); the readers below -- the store to W, the pair's diagonal
+            // update -- read the swizzled image
+            {
+                const int sc = tail_swz(c);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][4 * g + i] = XG(g);
+                for (int g = 0; g < 16; ++g) sh.Ls[16 * w + c][2 * ((2 * g + (i >> 1)) ^ sc) + (i & 1)] = XG(g);
+            }
             __syncthreads();
             TAIL_STAMP(9);
-            tail_tile_out(tile(xi, xl), ld, sh.Ls, tid);       // stores in flight ...
+            tail_tile_out<TS, true>(tile(xi, xl), ld, sh.Ls, tid);       // stores in flight ...
             TAIL_STAMP(10);
             if (pair) {
                 // ... while (tl,tl) takes the update by its own column tl-1 straight from LDS
+                const int isc = 2 * (i ^ tail_swz(c)), isw = 2 * (i ^ ((-w) & 3));
 #pragma unroll 2
                 for (int k8 = 0; k8 < 8; ++k8) {
-                    const int ko = 8 * k8 + 2 * i;
                     d2_t bD[4], aD[4];
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][ko]);
+                    for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][8 * k8 + isc]);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][ko]);
+                    for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][8 * k8 + isw]);
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll

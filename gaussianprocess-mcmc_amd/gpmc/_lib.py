@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgpmc.so')
+LIB_PATH = os.environ.get('GPMC_LIB') or os.path.join(_HERE, 'libgpmc.so')      # GPMC_LIB: another build of the same ABI (development A/B)
 CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
 
 KERNEL_RBF = 0
