@@ -325,7 +325,7 @@ def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
     plan.close()
     peak = 157.3 if dtype_name == 'f32' else FP64_MATRIX_PEAK_TF
     tf = n ** 3 / 3.0 / (ms * 1e-3) / 1e12
-    out = {'workload': '%s, N=%d, d=%d, %s' % ('RBF' if kernel == 'rbf' else 'ARD Matern-5/2', n, d, dtype_name),
+    out = {'name': name, 'workload': '%s, N=%d, d=%d, %s' % ('RBF' if kernel == 'rbf' else 'ARD Matern-5/2', n, d, dtype_name),
            'ms_per_eval': ms, 'evals_per_s': 1e3 / ms, 'steps': steps, 'tflops': tf, 'peak_tflops': peak, 'frac_of_peak': tf / peak,
            'enqueue': 'sync-each (result read before the next evaluation)', 'ms_per_eval_pipelined': ms_pipe}
     if dtype_name == 'f32':
@@ -337,14 +337,14 @@ def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
             raise SystemExit('%s: f32 log-marginal differs from f64 by %.3g relative (stated tolerance 2e-4)' % (name, rel))
         out['f32_vs_f64_rel_err'] = rel
         out['tolerance'] = 2e-4
-    if check_against_scipy:
+    def check():          # run after every config has been timed: the host BLAS threads it wakes disturb the timings that follow
         from oracle import sds_ref                                       # checker only
         ref = sds_ref.gp_log_marginal(X, g, pts[0], kernel=('rbf' if kernel == 'rbf' else 'matern52ard'))
         rel = abs(vals[0] - ref) / abs(ref)
         if rel > 1e-8:
             raise SystemExit('%s: parity failure vs SciPy: %r vs %r' % (name, vals[0], ref))
         out['scipy_rel_err'] = rel
-    return out
+    return out, (check if check_against_scipy else None)
 
 
 def timed_steps(plan, pts, steps, pipelined):
@@ -476,7 +476,6 @@ def main():
         torch.cuda.synchronize()
         dt_instr = time.perf_counter() - t1
         (k_ms, k_launches, k_flops), (d_ms, d_launches, d_flops) = _lib.profile_read()
-        gpmc.set_option('use_graph', 1)             # (everything after this pass records and replays again)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if (nccl or (world == 1 and dev is not None)) else 'cpu')
     if grouped:
@@ -494,6 +493,8 @@ def main():
         if not a.no_cpu_ref:
             cpu_ref = cpu_baseline_ref(X, g, pts, threads)
 
+    if not stub:
+        gpmc.set_option('use_graph', 1)             # (plans created from here on record and replay again)
     extra = {}
     if rank == 0 and not stub and not a.metric_only:
         # the O(N^2) kernel build alone, against its HBM roofline (bytes = s N^2 written + s N d read;
@@ -556,11 +557,13 @@ def main():
     if default_extras and a.n == 8192 and a.d == 2:
         # BASELINE.json's other configs at their per-GPU size, a few evaluations each (configs[1], configs[3] per GPU,
         # configs[4] per GPU)
-        extra['configs'] = {
-            'n2048': time_config('n2048', 2048, 2, 'rbf', 'f64', 40, True),
-            'n4096': time_config('n4096', 4096, 2, 'rbf', 'f64', 30, True),
-            'n16384_f32': time_config('n16384_f32', 16384, 8, 'matern52ard', 'f32', 6, False),
-        }
+        timed = [time_config('n2048', 2048, 2, 'rbf', 'f64', 40, True),
+                 time_config('n4096', 4096, 2, 'rbf', 'f64', 30, True),
+                 time_config('n16384_f32', 16384, 8, 'matern52ard', 'f32', 6, False)]
+        for _, chk in timed:
+            if chk:
+                chk()
+        extra['configs'] = {o['name']: o for o, _ in timed}
     if a.chain > 0 and rank == 0 and not stub:
         # chain-level cross-check: the real sampler from the framework's initial point; targets are a
         # bounded series in the reference's data range, one aux_var_model + several full SDS proposals per iteration

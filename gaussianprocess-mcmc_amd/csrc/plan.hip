@@ -106,6 +106,9 @@ static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
 // host launch paths, which let a +12 % exec through).  One-stream schedules have nothing to alias: they are recorded
 // once and never timed against anything.
 static int record_sequence(gpmc_plan* p) {
+    // (a plan whose eager evaluations ran while use_graph was off has no yardstick: its first recording is accepted)
+    const bool have_yardstick = p->ev0 != nullptr && p->eager_ms > 0.f;
+    if (!p->ev0) { GPMC_HIP(hipEventCreate(&p->ev0)); GPMC_HIP(hipEventCreate(&p->ev1)); }
     const int max_forkjoin = (g_opt.replay_form && forkjoin_allowed()) ? 2 : 0;
     for (int attempt = 0; attempt <= max_forkjoin; ++attempt) {
         const int form = attempt < max_forkjoin ? Sched::FORKJOIN : Sched::SEGMENTS;
@@ -123,7 +126,7 @@ static int record_sequence(gpmc_plan* p) {
         GPMC_HIP(hipEventElapsedTime(&p->replay_ms, p->ev0, p->ev1));
         p->record_attempts = attempt + 1;
         p->recorded_form = form;
-        if (form == Sched::SEGMENTS || !two_streams || p->replay_ms <= 1.04f * p->eager_ms + 0.02f) break;
+        if (form == Sched::SEGMENTS || !two_streams || !have_yardstick || p->replay_ms <= 1.04f * p->eager_ms + 0.02f) break;
         rc = p->sched.drop_ops();
         if (rc) return rc;
     }
