@@ -26,7 +26,7 @@ template <int WGM, int WGN, int RG, int CG, bool EPI, int KCH = 2>
 __global__ void __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 4) ? 2 : 1)
 gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, const double* Cin,
                 int ldcin, double* C, int ldc, int K, int ntc, int tri, double alpha, int beta, int n_true,
-                double diag_add, int ktri, int prio_cols, unsigned* __restrict__ gflag) {
+                double diag_add, int ktri, int prio_cols, unsigned* __restrict__ gflag, double* C2) {
     constexpr int BM = WGM * RG * 4, BN = WGN * CG * 16;
     constexpr int NT = WGM * WGN * 64;                     // threads per workgroup (256 or 512)
     constexpr int BKE = 8 * KCH;                           // k elements per stage
@@ -191,6 +191,7 @@ gemm4_nt_kernel(const double* __restrict__ A, int lda, const double* __restrict_
                 if (gr >= n_true || gc >= n_true) v = (gr == gc) ? 1.0 : 0.0;
             }
             C[(size_t)gr * ldc + gc] = v;
+            if (EPI) if (C2) C2[(size_t)gr * ldc + gc] = v;      // second copy of the result (gpmc_syrk_tri2), same ld
         }
     if (is_prio) {
         // publish: plain stores -> every storing wave drains -> workgroup barrier -> one lane's agent-scope release

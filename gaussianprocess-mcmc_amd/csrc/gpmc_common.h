@@ -211,7 +211,7 @@ template <typename T>
 int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C, int n, int np_, int ldc,
               hipStream_t s);
 template <typename T>
-int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s);
+int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s, T* C2 = nullptr);
 template <typename T>
 int symv_lower(const T* W, int n, int ldw, const T* x, T* y, hipStream_t s);
 template <typename T>

@@ -357,6 +357,14 @@ int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int 
 int gpmc_syrk_tri_f32(const float* P, int ldp, float diag_add, float* C, int n, int np_, int ldc, gpmc_stream_t stream) {
     return syrk_tri<float>(P, ldp, diag_add, C, n, np_, ldc, S_(stream));
 }
+int gpmc_syrk_tri2_f64(const double* P, int ldp, double diag_add, double* C, double* C2, int n, int np_, int ldc, gpmc_stream_t stream) {
+    GPMC_ARG(C2 != nullptr && C2 != C, 5);
+    return syrk_tri<double>(P, ldp, diag_add, C, n, np_, ldc, S_(stream), C2);
+}
+int gpmc_syrk_tri2_f32(const float* P, int ldp, float diag_add, float* C, float* C2, int n, int np_, int ldc, gpmc_stream_t stream) {
+    GPMC_ARG(C2 != nullptr && C2 != C, 5);
+    return syrk_tri<float>(P, ldp, diag_add, C, n, np_, ldc, S_(stream), C2);
+}
 int gpmc_logdet_quad_f64(const double* W, int n, int ldw, const double* alpha_dev, const int* info_dev,
                          double* out_dev, gpmc_stream_t stream) {
     return logdet_quad<double>(W, n, ldw, alpha_dev, info_dev, out_dev, S_(stream));

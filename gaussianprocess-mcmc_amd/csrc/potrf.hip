@@ -191,7 +191,7 @@ constexpr int GM_ROWB = 144;  // LDS bytes per tile row: 128 data + 16 pad
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, const T* Cin, int ldcin,
-               T* C, int ldc, int K, int ntc, int tri, T alpha, int beta, int n_true, T diag_add, int ktri) {
+               T* C, int ldc, int K, int ntc, int tri, T alpha, int beta, int n_true, T diag_add, int ktri, T* C2) {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     using frag_t = typename M::frag_t;
@@ -321,13 +321,14 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ B, int ld
                     if (gr >= n_true || gc >= n_true) v = (gr == gc) ? (T)1 : (T)0;
                 }
                 C[(size_t)gr * ldc + gc] = v;
+                if (EPI) if (C2) C2[(size_t)gr * ldc + gc] = v;
             }
 }
 
 template <typename T, int WGM, int WGN, int TM, int TN, bool EPI>
 static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, int ldcin, T* C, int ldc, int mrows,
                        int ncols, int K, int tri, T alpha, int beta, int n_true, T diag_add, hipStream_t s,
-                       int ktri = 0, int lds_pad = 0, int prio_cols = 0, unsigned* gflag = nullptr) {
+                       int ktri = 0, int lds_pad = 0, int prio_cols = 0, unsigned* gflag = nullptr, T* C2 = nullptr) {
     constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
     constexpr int BK = 128 / (int)sizeof(T);
     if (mrows <= 0 || ncols <= 0) return 0;
@@ -372,7 +373,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attr8_done = true;
                 }
                 hipLaunchKernelGGL(k8, dim3(nblk), dim3(512), smem + (size_t)lds_pad, s, A, lda, B, ldb, Cin, ldcin,
-                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr);
+                                   C, ldc, K, ntc, tri, alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr, C2);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -386,7 +387,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
                     attrs_done = true;
                 }
                 hipLaunchKernelGGL(ks, dim3(nblk), dim3(256), smems, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                                   alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr);
+                                   alpha, beta, n_true, diag_add, ktri, 0, (unsigned*)nullptr, C2);
                 GPMC_LAUNCH_CHECK();
                 return 0;
             }
@@ -399,7 +400,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
             }
             const size_t smem4 = smem + ((BM == 128) ? (size_t)lds_pad : 0);
             hipLaunchKernelGGL(k4, dim3(nblk), dim3(256), smem4, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri,
-                               alpha, beta, n_true, diag_add, ktri, gflag ? prio_cols : 0, gflag);
+                               alpha, beta, n_true, diag_add, ktri, gflag ? prio_cols : 0, gflag, C2);
             GPMC_LAUNCH_CHECK();
             return 0;
         }
@@ -412,7 +413,7 @@ static int launch_gemm(const T* A, int lda, const T* B, int ldb, const T* Cin, i
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, s, A, lda, B, ldb, Cin, ldcin, C, ldc, K, ntc, tri, alpha,
-                       beta, n_true, diag_add, ktri);
+                       beta, n_true, diag_add, ktri, C2);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
@@ -1069,13 +1070,13 @@ int syrk_diff(const T* D, int ldd, const T* P, int kp, int ldp, T diag_add, T* C
 // C = diag_add I - P P^T for an upper-trapezoidal P (row i zero left of column i; n x np_ inside an np_ x np_ padded
 // square whose padding becomes the identity): the products of a lower tile start at its first row -> N^3/3 flops.
 template <typename T>
-int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s) {
+int syrk_tri(const T* P, int ldp, T diag_add, T* C, int n, int np_, int ldc, hipStream_t s, T* C2) {
     GPMC_ARG(P && C, 1);
     GPMC_ARG(n > 0 && n <= np_ && np_ % GPMC_PAD == 0, 5);
     GPMC_ARG(ldc >= np_ && ldp >= np_, 7);
     if (np_ > g_opt.small_tile_m)
-        return launch_gemm<T, 2, 2, 4, 4, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1);
-    return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1);
+        return launch_gemm<T, 2, 2, 4, 4, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1, 0, 0, nullptr, C2);
+    return launch_gemm<T, 2, 2, 2, 2, true>(P, ldp, P, ldp, nullptr, 0, C, ldc, np_, np_, np_, 1, (T)-1, 0, n, diag_add, s, 1, 0, 0, nullptr, C2);
 }
 
 // rows (nrows x np_, ldr) <- rows L^-T with L the lower triangle of W (f64): 64-column blocks, MFMA TRSM on the
@@ -1144,8 +1145,8 @@ int revt_lower_f64(const double* L, int n, int ld, double* Lt, int ldo, hipStrea
 
 template int potrf<double>(double*, int, int, int, int*, void*, hipStream_t, int, Sched*, int);
 template int potrf<float>(float*, int, int, int, int*, void*, hipStream_t, int, Sched*, int);
-template int syrk_tri<double>(const double*, int, double, double*, int, int, int, hipStream_t);
-template int syrk_tri<float>(const float*, int, float, float*, int, int, int, hipStream_t);
+template int syrk_tri<double>(const double*, int, double, double*, int, int, int, hipStream_t, double*);
+template int syrk_tri<float>(const float*, int, float, float*, int, int, int, hipStream_t, float*);
 template int syrk_diff<double>(const double*, int, const double*, int, int, double, double*, int, int, int, hipStream_t);
 template int syrk_diff<float>(const float*, int, const float*, int, int, float, float*, int, int, int, hipStream_t);
 

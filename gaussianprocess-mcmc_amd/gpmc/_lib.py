@@ -69,6 +69,8 @@ def _sig(lib):
         'gpmc_seq_launch': ([P, P], I), 'gpmc_seq_retire': ([P], I),
         'gpmc_syrk_tri_f64': ([P, I, c_double, P, I, I, I, P], I),
         'gpmc_syrk_tri_f32': ([P, I, c_float, P, I, I, I, P], I),
+        'gpmc_syrk_tri2_f64': ([P, I, c_double, P, P, I, I, I, P], I),
+        'gpmc_syrk_tri2_f32': ([P, I, c_float, P, P, I, I, I, P], I),
         'gpmc_syrk_diff_f64': ([P, I, P, I, I, c_double, P, I, I, I, P], I),
         'gpmc_syrk_diff_f32': ([P, I, P, I, I, c_float, P, I, I, I, P], I),
         'gpmc_symv_lower_f64': ([P, I, I, P, P, P], I), 'gpmc_symv_lower_f32': ([P, I, I, P, P, P], I),

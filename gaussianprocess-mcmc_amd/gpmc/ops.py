@@ -142,8 +142,15 @@ def unpack_rows(W, np_, nrhs, n, out=None):
     return out
 
 
-def syrk_tri(P, C, n, np_, diag_add=0.0):
-    """C = diag_add*I - P P^T for an upper-trapezoidal P (np_ x np_ rows of gpmc_potrf_tri)"""
+def syrk_tri(P, C, n, np_, diag_add=0.0, C2=None):
+    """C = diag_add*I - P P^T for an upper-trapezoidal P (np_ x np_ rows of gpmc_potrf_tri); with ``C2`` the result is
+    written to both matrices (same leading dimension)"""
+    if C2 is not None:
+        if C2.dtype != C.dtype or C2.stride(0) != C.stride(0) or C2.data_ptr() == C.data_ptr():
+            raise ValueError('syrk_tri: C2 must be another matrix of the same dtype and leading dimension')
+        check(_fn('syrk_tri2', C.dtype)(P.data_ptr(), P.stride(0), float(diag_add), C.data_ptr(), C2.data_ptr(), n, np_,
+                                        C.stride(0), stream_ptr()), 'gpmc_syrk_tri2')
+        return C
     check(_fn('syrk_tri', C.dtype)(P.data_ptr(), P.stride(0), float(diag_add), C.data_ptr(), n, np_, C.stride(0),
                                    stream_ptr()), 'gpmc_syrk_tri')
     return C

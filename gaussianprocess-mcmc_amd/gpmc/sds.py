@@ -35,6 +35,14 @@ from . import _lib, covK, ops
 R_JITTER = 1e-11          # sliceSample.py:205
 
 
+class _NullCtx(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class SDSWorkspace(object):
     def __init__(self, x, kernel='rbf', dtype=torch.float64, form='inv'):
         ops.require_gpu()
@@ -75,7 +83,9 @@ class SDSWorkspace(object):
         self.gs = torch.zeros(n, dtype=dtype, device=dev)
         self.prop_f = torch.zeros(n, dtype=dtype, device=dev)
         self.Rdiag = torch.zeros(n, dtype=dtype, device=dev)
-        self.R0 = None                                            # copy of R for the jitter schedule, allocated on first use
+        # second copy of -P P^T, written by the same launch that forms R: chol(R + 1e-11 I) works in place and needs the
+        # jitter schedule about one proposal in three at N = 8192, and restoring R is a copy instead of another N^3/3
+        self.R0 = torch.zeros((np_, np_), dtype=dtype, device=dev) if form == 'inv' else None
         # inputs of the recorded proposal sequence (fixed addresses) and its results in pinned host memory
         self.f_in = torch.zeros(n, dtype=dtype, device=dev)
         self.g_in = torch.zeros(n, dtype=dtype, device=dev)
@@ -84,6 +94,12 @@ class SDSWorkspace(object):
         self._seq = None
         self._seq_stream = None
         self._proposals = 0
+        if self.R0 is not None:
+            # the jitter schedule's own launches, once on zeros: their code objects load here, not inside the first
+            # proposal that needs them (~15 ms on a fresh process)
+            float(self.Rdiag.mean())
+            self.R0.diagonal()[:n].copy_(self.Rdiag)
+            self.WR[:np_].copy_(self.R0)
         self._last_stream = None   # the stream the last sequence went to, when it is not the current one
         self._dirty = False        # a failed factorisation of K + S has run: its riding rows may hold NaN anywhere
 
@@ -137,7 +153,7 @@ class SDSWorkspace(object):
         g = self.g_in
         rows = self.WA[self.rows0:self.rows0 + np_]
         if self.form == 'inv':
-            ops.syrk_tri(rows, self.WR, n, np_, 0.0)              # -P P^T (identity on the padding) ...
+            ops.syrk_tri(rows, self.WR, n, np_, 0.0, C2=self.R0)  # -P P^T (identity on the padding), kept twice ...
             self.WR.diagonal()[:n].add_(self.kpS[1])              # ... + s_A I, the shift read on the device
             # m = R S^-1 g = (s_A I - P P^T) g / s = (s_A / s)(g - P alpha), alpha = L^-1 g the riding row (P^T g = s_A alpha):
             # one triangular product, R itself is not read.  s_A = s unless K + S needed jitter.
@@ -177,7 +193,7 @@ class SDSWorkspace(object):
         the jitchol schedule the reference pins (pyGPs 1.3.4): mean(diag) * 1e-9 added, x10 per retry, ``maxtries``
         retries, then np.linalg.LinAlgError propagates to the caller exactly as in the reference.  R has eigenvalues at
         rounding level, so that schedule is part of normal operation (about a third of the bench's points at N = 8192):
-        on a failure R is rebuilt once (the factorisation is in place), kept, and restored for every further retry.
+        the launch that forms R writes it twice (gpmc_syrk_tri2), and a failure restores R from the second copy for every retry.
         (``need_eta`` is kept for the signature: eta rides on the factorisation of R either way.)"""
         if f is not self.f_in:
             self.f_in.copy_(f)
@@ -215,13 +231,15 @@ class SDSWorkspace(object):
             if not rdiag_mean > 0:
                 raise np.linalg.LinAlgError('not pd: non-positive diagonal elements')
             jitter = rdiag_mean * 1e-9
-            self._make_R()                                       # the failed attempt overwrote R
-            if self.R0 is None:
-                self.R0 = torch.empty((self.np_, self.np_), dtype=self.dtype, device=self.WR.device)
-            self.R0.copy_(self.WR[:self.np_])
+            if self.form == 'inv':                               # the failed attempt overwrote R: R0 and Rdiag restore it
+                self.R0.diagonal()[:self.n].copy_(self.Rdiag)
+            else:
+                self._make_R()
+                if self.R0 is None:
+                    self.R0 = torch.empty((self.np_, self.np_), dtype=self.dtype, device=self.WR.device)
+                self.R0.copy_(self.WR[:self.np_])
             for t in range(maxtries):
-                if t:
-                    self.WR[:self.np_].copy_(self.R0)
+                self.WR[:self.np_].copy_(self.R0)
                 self._chol_R(jitter)
                 if _lib.check_info(self.infoR.item()) == 0:
                     break
@@ -311,12 +329,20 @@ class SDSWorkspace(object):
         else:
             self._sequence()
         self._proposals += 1
-        G = self._finish(maxtries)
-        if self._retried or self._sA != self.Sii:
-            # a jitter retry re-factored R (or K + S) after the sequence had formed f': form it again from the final factors
-            ops.trmv_lower(self.WR, self.n, self.ita_in, self.m, self.prop_f)
-            return G, self.prop_f.cpu().numpy()
-        return G, self.res_host[8:8 + self.n].numpy().astype(np.float64, copy=True)
+        # whatever follows a replay -- reading the results, the jitter schedules if a pivot failed -- stays on the replay's
+        # stream (the eager retries of a replayed proposal took 12 ms on the default stream against 8 after eager launches)
+        side = self._last_stream
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            G = self._finish(maxtries)
+            if self._retried or self._sA != self.Sii:
+                # a jitter retry re-factored R (or K + S) after the sequence had formed f': form it again from the final factors
+                ops.trmv_lower(self.WR, self.n, self.ita_in, self.m, self.prop_f)
+                fp = self.prop_f.cpu().numpy()
+            else:
+                fp = self.res_host[8:8 + self.n].numpy().astype(np.float64, copy=True)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return G, fp
 
     @property
     def eta(self):

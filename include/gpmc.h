@@ -172,6 +172,13 @@ int gpmc_syrk_tri_f64(const double* P, int ldp, double diag_add, double* C, int 
                       gpmc_stream_t stream);
 int gpmc_syrk_tri_f32(const float* P, int ldp, float diag_add, float* C, int n, int np_, int ldc,
                       gpmc_stream_t stream);
+/* the same product written to two matrices of the same leading dimension (C2 != C): chol(R + 1e-11 I) works in place and
+ * fails at rounding-level eigenvalues about one proposal in three at N = 8192 (jitchol's schedule then adds jitter,
+ * sliceSample.py:205 -> pyGPs jitchol); the second copy lets the retry restore R instead of forming it again. */
+int gpmc_syrk_tri2_f64(const double* P, int ldp, double diag_add, double* C, double* C2, int n, int np_, int ldc,
+                       gpmc_stream_t stream);
+int gpmc_syrk_tri2_f32(const float* P, int ldp, float diag_add, float* C, float* C2, int n, int np_, int ldc,
+                       gpmc_stream_t stream);
 
 /* ---- a6/a10: symmetric / triangular matrix-vector products on workspace matrices ----------------
  * symv_lower:  y = A_sym x   using only the lower triangle of A (n x n inside W)   (m = R (g/S), :204)

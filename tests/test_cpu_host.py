@@ -70,6 +70,7 @@ assert L.gpmc_potrf_f64(None, 256, 256, 256, None, None, None) < 0 and b'bad arg
 assert L.gpmc_potrf_tri_f64(None, 256, 256, 256, 128, None, None, None) < 0
 assert L.gpmc_kbuild_f64(0, None, 0, 0, 0, None, 0, 0, None, None, 0, 0, 0, 0, None) != 0
 assert L.gpmc_syrk_tri_f64(None, 0, ctypes.c_double(0.), None, 0, 0, 0, None) < 0
+assert L.gpmc_syrk_tri2_f64(None, 0, ctypes.c_double(0.), None, None, 0, 0, 0, None) < 0
 assert L.gpmc_trsm_rows_f64(None, 0, 0, None, 0, 0, None) < 0 and L.gpmc_gemm_nt_f64(None, 0, None, 0, None, 0, 0, 0, 0, None) < 0
 h = P()
 assert L.gpmc_plan_create(ctypes.byref(h), 7, 10, 2, 8, None, 0, None) < 0      # bad kernel id

@@ -383,6 +383,18 @@ def test_syrk_tri_matches_dense(gp, n):
         pad = Cn[n:, :]
         assert np.all(np.diag(Cn)[n:] == 1.0)
         assert np.all(np.tril(pad[:, :n]) == 0) or np.all(pad[:, :n][np.tril_indices_from(pad[:, :n])] == 0)
+    # the two-output form (the second copy of R the SDS jitter schedule restores from): both bit-identical to the above
+    for dt in (torch.float64, torch.float32):
+        C1 = torch.full((np_ + ops.PAD, np_), float('nan'), dtype=dt, device='cuda')
+        Ca = torch.full((np_ + ops.PAD, np_), float('nan'), dtype=dt, device='cuda')
+        Cb = torch.full((np_, np_), float('nan'), dtype=dt, device='cuda')
+        ops.syrk_tri(Pw.to(dt), C1, n, np_, 0.25)
+        ops.syrk_tri(Pw.to(dt), Ca, n, np_, 0.25, C2=Cb)
+        one, a, b = C1[:np_].cpu().numpy(), Ca[:np_].cpu().numpy(), Cb.cpu().numpy()
+        lowp = np.tril_indices(np_)
+        assert np.array_equal(one[lowp], a[lowp]) and np.array_equal(one[lowp], b[lowp])
+    with pytest.raises(ValueError):
+        ops.syrk_tri(Pw, C, n, np_, 0.25, C2=C)
 
 
 def test_potrf_tri_argument_checks(gp):
