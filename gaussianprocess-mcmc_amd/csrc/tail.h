@@ -668,20 +668,28 @@ tail_kernel(TS* __restrict__ W, int ld, int k0, int T, int R, int H, int tri0, u
             if (pair) {
                 // ... while (tl,tl) takes the update by its own column tl-1 straight from LDS
                 const int isc = 2 * (i ^ tail_swz(c)), isw = 2 * (i ^ ((-w) & 3));
-#pragma unroll 2
+                // operands of k step k8 + 1 are read before the MFMAs of k step k8 are issued (scheduling barriers): the LDS
+                // round trip, exposed eight times when every step read its own operands first, runs under 20 MFMAs
+                d2_t bDk[8][4], aDk[8][4];
+                auto u_reads = [&](int k8) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) bDk[k8][h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][8 * k8 + isc]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) aDk[k8][m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][8 * k8 + isw]);
+                };
+                u_reads(0);
+#pragma unroll
                 for (int k8 = 0; k8 < 8; ++k8) {
-                    d2_t bD[4], aD[4];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) bD[h] = *reinterpret_cast<const d2_t*>(&sh.Ls[16 * h + c][8 * k8 + isc]);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) aD[m] = *reinterpret_cast<const d2_t*>(&sh.Ls[4 * (w + 4 * m) + ia][8 * k8 + isw]);
+                    if (k8 < 7) u_reads(k8 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
                             for (int h = 0; h <= m; ++h)
-                                D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aD[m][e2], bD[h][e2], D[m][h], 0, 0, 0);
+                                D[m][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(-aDk[k8][m][e2], bDk[k8][h][e2], D[m][h], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             TAIL_STAMP(5);
