@@ -247,6 +247,7 @@ class SDSWorkspace(object):
             else:
                 raise np.linalg.LinAlgError('not positive definite, even with jitter.')
             self._retried = True
+            self._jitR = jitter                                  # what the schedule added on top of the 1e-11
         return G
 
     # ------------------------------------------------------------------ one proposal of the sampler's inner loop

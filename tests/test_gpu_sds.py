@@ -410,6 +410,53 @@ def test_recorded_proposal_sequence_matches_eager(gp, n):
     assert abs(got[2][0] - ref) <= 1e-8 * abs(ref)
 
 
+@pytest.mark.parametrize('hyp,min_steps', [([1.0, 100.0, 1.0], 0), ([2.0, 1000.0, 1.0], 1)])
+def test_R_jitter_schedule_restores_R_from_its_second_copy(gp, hyp, min_steps):
+    """chol(R + 1e-11 I) (sliceSample.py:205) fails when rounding pushes R's smallest eigenvalues below -1e-11 (large signal
+    variance); jitchol then adds mean(diag R) * 1e-9, x10 per further attempt, to the ORIGINAL matrix.  The factorisation is
+    in place, so the 'inv' form restores R from the second copy its SYRK launch wrote (gpmc_syrk_tri2) plus the saved
+    diagonal; the 'syrk' form forms R again.  Pinned: the schedule ran (and, for the second point, more than once), the
+    jitter is on the schedule, C C^T = R + (1e-11 + jitter) I against NumPy's R, both forms agree, and the recorded
+    proposal path returns the same G' and f' as the eager one for such a point, bit for bit."""
+    n = 700
+    rng = np.random.RandomState(5)
+    X = rng.uniform(0, 10, (n, 2))
+    g0 = rng.standard_normal(n) * 5
+    f = torch.as_tensor(rng.standard_normal(n)).cuda()
+    g = torch.as_tensor(g0).cuda()
+    ell, sf, sn = hyp
+    K = sds_ref.covK.RBF(np.log(ell), np.log(sf)).getCovMatrix(x=X, mode='train')
+    s = sn ** 2
+    Rn = s * np.eye(n) - s * s * np.linalg.inv(K + s * np.eye(n))            # S - S (K+S)^-1 S (== K - V^T V, :197-198)
+    out = {}
+    for form in ('inv', 'syrk'):
+        ws = gp['sds'].SDSWorkspace(X, form=form)
+        G = ws.aux_var_model(f, hyp, g, need_eta=True)
+        assert ws._retried
+        jit = ws._jitR
+        steps = np.log10(jit / (np.diag(Rn).mean() * 1e-9))
+        assert abs(steps - round(steps)) < 1e-6 and min_steps <= round(steps) <= 4, (jit, steps)
+        C = ws.chol_R().cpu().numpy()
+        np.testing.assert_allclose(C @ C.T, Rn + (1e-11 + jit) * np.eye(n), rtol=0, atol=2e-7)
+        fp = ws.propose_f(ws.eta.clone())
+        assert float((fp - f).abs().max()) < 1e-4
+        out[form] = (G, jit, C)
+        del ws
+    assert out['inv'][0] == out['syrk'][0] and abs(out['inv'][1] / out['syrk'][1] - 1) < 1e-9
+    assert np.abs(out['inv'][2] @ out['inv'][2].T - out['syrk'][2] @ out['syrk'][2].T).max() < 1e-8
+    # the sampler's loop body: eager, recording, replays -- all through the same schedule
+    ws, ws2 = gp['sds'].SDSWorkspace(X), gp['sds'].SDSWorkspace(X)
+    ws.aux_var_model(f, [1.0, 10.0, 1.2], g, need_eta=True)
+    ita = ws.eta.clone()
+    ws.begin(f, g, ita)
+    for pt in ([1.0, 10.0, 1.2], hyp, [1.3, 9.0, 1.1], hyp, hyp):
+        Gp, fp = ws.proposal(pt)
+        assert ws._retried == (pt is hyp)
+        Gr = ws2.aux_var_model(f, pt, g, need_eta=False)
+        assert Gp == Gr and np.array_equal(fp, ws2.propose_f(ita).cpu().numpy())
+    assert ws._seq is not None
+
+
 def test_sds_forms_agree_at_size(gp):
     """N = 4096 (big tiles, trapezoidal riding rows, triangular SYRK): the two algebraic forms of the SDS block give the
     same L bit for bit (the riding rows do not feed back), the same log-marginal, m to 1e-9 and R + 1e-11 I to 1e-8 in
