@@ -159,6 +159,9 @@ constexpr int NB_IN = 64;  // inner (diagonal-block) size of the Cholesky
 // device scratch of potrf(): 16x16 inverse tiles (three-kernel panel path) | parked diagonal factors | parked L21
 // blocks | sync words of the tail kernel
 size_t potrf_scratch_bytes(int np_);
+// set around a factorisation whose launches must not wait for one another inside the kernels (plan.hip: every plan but
+// the process's one hand-over owner): the look-ahead hand-over is then the stream-ordered one, as with shared_card
+extern bool g_ordered_handover;
 extern unsigned long long* g_tail_dbg;   // diagnostic stamp buffer of the tail kernel (nullptr in production)
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -13,6 +13,7 @@
 #include <new>
 
 #include "gpmc_common.h"
+#include <map>
 
 namespace gpmc {
 
@@ -59,14 +60,34 @@ struct gpmc_plan {
     int record_attempts, recorded_form;
     int evals;
     bool have_data;
+    bool ordered;         // hand-over mode of the launches being enqueued / of the recorded sequence (plans_must_order)
     unsigned char slot_busy[64];   // PLAN_SLOTS: 1 while an evaluation using the slot's staging / result is in flight
     hipEvent_t slot_ev[64];        // recorded behind the slot's result copy
 };
 
+// The in-launch hand-over of the look-ahead (potrf.hip, dag_ahead) lets a panel launch's workgroups wait, resident, for
+// flags of the trailing GEMM that runs beside it.  A factorisation that has the card to itself always finishes; next to
+// ANY other launch with resident waiting workgroups -- another process's (round 2's two-processes-on-one-card abort), or
+// another plan of this process evaluating concurrently on its own stream, its tile-DAG tail launch included -- the
+// waiters of both can hold every CU slot while the GEMM they wait for cannot place a block.  So the in-launch form is
+// used only while ONE workspace has live plans in the process (plans on the same workspace cannot run concurrently:
+// LogMarginalPlan's settle creates its second candidate there); as soon as a second one exists every plan hands over in
+// stream order (what option shared_card selects unconditionally), and a plan whose recorded sequence was made in the
+// other mode records again at its next evaluation.
+static std::map<char*, int> g_live_ws;
+static bool plans_must_order() { return g_live_ws.size() > 1; }
+
 namespace gpmc {
+
+struct OrderedScope {
+    bool saved;
+    explicit OrderedScope(bool on) : saved(g_ordered_handover) { g_ordered_handover = on; }
+    ~OrderedScope() { g_ordered_handover = saved; }
+};
 
 template <typename T>
 static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
+    OrderedScope ordered(p->ordered);
     const PlanLayout& L = p->L;
     T* W = reinterpret_cast<T*>(p->ws + L.off_W);
     const T* X = reinterpret_cast<const T*>(p->ws + L.off_X);
@@ -430,6 +451,7 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     p->ws = reinterpret_cast<char*>(workspace);
     p->stream = S_(stream);
     p->recorded = false; p->evals = 0; p->have_data = false;
+    p->ordered = false;
     p->ev0 = p->ev1 = nullptr; p->eager_ms = p->replay_ms = 0.f; p->record_attempts = 0; p->recorded_form = -1;
     memset(p->slot_busy, 0, sizeof(p->slot_busy));
     memset(p->slot_ev, 0, sizeof(p->slot_ev));
@@ -453,6 +475,8 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
                        (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
     if (e != hipSuccess) { (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    ++g_live_ws[p->ws];
+    p->ordered = plans_must_order();
     *out = p;
     return 0;
 }
@@ -489,8 +513,21 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
         for (int i = 0; i < nk; ++i) f[i] = (float)kparams_host[i];
         f[2 + PLAN_MAXD] = (float)slot;
     }
-    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)(2 + PLAN_MAXD + 1) * p->es, hipMemcpyHostToDevice, p->stream));
     int rc = 0;
+    if (p->ordered != plans_must_order()) {
+        // another plan appeared (or the last other one went): the sequence recorded in the old mode is retired and this plan
+        // starts over -- two eager evaluations (the second one the yardstick), then a new recording
+        if (p->recorded) {
+            GPMC_HIP(hipStreamSynchronize(p->stream));
+            if (p->sched.panel) GPMC_HIP(hipStreamSynchronize(p->sched.panel));
+            rc = p->sched.drop_ops();
+            if (rc) return rc;
+            p->recorded = false;
+        }
+        p->evals = 0;
+        p->ordered = plans_must_order();
+    }
+    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)(2 + PLAN_MAXD + 1) * p->es, hipMemcpyHostToDevice, p->stream));
     const bool graph_ok = g_opt.use_graph && p->stream != nullptr;   // the NULL stream cannot be captured
     if (!graph_ok || p->evals < 2) {
         // eager launches: the first evaluation always (it sets the kernels' attributes, which a capture would record);
@@ -592,8 +629,14 @@ int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld) {
     return 0;
 }
 
+int gpmc_plan_handover_in_launch(const gpmc_plan* p) { return (p != nullptr && !plans_must_order()) ? 1 : 0; }
+
 int gpmc_plan_destroy(gpmc_plan* p) {
     if (!p) return 0;
+    {
+        auto it = g_live_ws.find(p->ws);
+        if (it != g_live_ws.end() && --it->second == 0) g_live_ws.erase(it);
+    }
     (void)hipStreamSynchronize(p->stream);
     if (p->sched.panel) (void)hipStreamSynchronize(p->sched.panel);
     (void)p->sched.destroy();     // retires the recorded execs (drop_ops), then the events and the panel stream

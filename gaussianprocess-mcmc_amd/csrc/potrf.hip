@@ -41,6 +41,7 @@ namespace gpmc {
 Options g_opt;
 thread_local char g_err[512] = {0};
 
+bool g_ordered_handover = false;
 unsigned long long* g_tail_dbg = nullptr;    // diagnostic only (gpmc_debug_tail_stamps): stamp buffer of the next launches
 static size_t potrf_scratch_base(int np_) { return (size_t)(np_ / NB_IN + 1) * (1024 + 4096 + 4096) * sizeof(double); }
 size_t potrf_scratch_bytes(int np_) { return potrf_scratch_base(np_) + TAIL_SYNC_BYTES + 64; }
@@ -738,7 +739,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                            (unsigned)g_opt.tail_spin_limit, gflag, gmt, tflags,                                            \
                            (dead_row64 >= k0 / NB_IN && dead_row64 < k0 / NB_IN + Rt) ? dead_row64 - k0 / NB_IN : -1,       \
                            (ride_waves < 4 && np_ / NB_IN < k0 / NB_IN + Rt) ? (np_ - k0) / NB_IN : -1, ride_waves,          \
-                           (g_opt.tail_xcd && !g_opt.shared_card && st == s && workers >= 256) ? 8 : 1)
+                           (g_opt.tail_xcd && !g_opt.shared_card && !g_ordered_handover && st == s && workers >= 256) ? 8 : 1)
         // variants (tail.h): the 4x4x4 accumulation (cross-checks only); the 16x16x4 accumulation; the same with the next
         // column's operands prefetched -- for launches whose time is their bulk, not their pivot chain
         const bool pre = g_opt.tail_acc16 && sizeof(T) == 8 && (st == s ? (g_opt.tail_prefetch_t > 0 && Tt >= g_opt.tail_prefetch_t)
@@ -856,7 +857,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         // same slots that wait can outlast the spin limit.  The hand-over is then the event edge ge (stream order): no
         // workgroup of a panel launch ever waits for another kernel.
         auto handover_words = [&](int k1, int k2) -> size_t {
-            if (sizeof(T) != 8 || !g_opt.dag_ahead || g_opt.shared_card || !g_opt.dag_hist || g_opt.gemm_impl != 1 ||
+            if (sizeof(T) != 8 || !g_opt.dag_ahead || g_opt.shared_card || g_ordered_handover || !g_opt.dag_hist || g_opt.gemm_impl != 1 ||
                 k2 >= np_ || hand_over(k2))
                 return 0;
             const int rows = mp_at(k1) - k2;

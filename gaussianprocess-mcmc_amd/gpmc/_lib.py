@@ -86,6 +86,7 @@ def _sig(lib):
                                  ctypes.POINTER(I)], I),
         'gpmc_plan_destroy': ([P], I),
         'gpmc_graveyard_stats': ([ctypes.POINTER(I), ctypes.POINTER(c_size_t)], I),
+        'gpmc_plan_handover_in_launch': ([P], I),
         'gpmc_debug_panel_stamps': ([P, I, I, I, I, P, P, I, P, P], I),
         'gpmc_debug_tail_stamps': ([P], I),
         'gpmc_debug_graph_churn': ([P, I, I, I], I),

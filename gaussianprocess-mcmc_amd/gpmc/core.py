@@ -107,6 +107,13 @@ class LogMarginalPlan(object):
             _lib.check(L.gpmc_plan_result(self._h, i, out), 'gpmc_plan_result')
         return 1e3 * (time.perf_counter() - t0) / reps
 
+    @property
+    def handover_in_launch(self):
+        """True while this plan's look-ahead uses the in-launch hand-over: only as long as no plan on another workspace
+        is alive in the process (include/gpmc.h, gpmc_plan_handover_in_launch) -- plans that may evaluate concurrently
+        hand over in stream order"""
+        return bool(_lib.lib().gpmc_plan_handover_in_launch(self._h))
+
     def record_info(self):
         """(eager ms, first replay ms, recording attempts, form: 2 fork/join / 1 linear segments / -1 none yet)"""
         L = _lib.lib()

@@ -245,6 +245,14 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host);
 /* device pointer / geometry of the factored workspace of the last evaluation (for callers that go on
  * to use L): W, mp, np_, ld */
 int gpmc_plan_workspace(gpmc_plan* p, void** W, int* mp, int* np_, int* ld);
+/* Several plans of one process may evaluate concurrently, each on its own stream (k independent chains on one card).  The
+ * look-ahead's in-launch hand-over -- workgroups of a panel launch waiting, resident, for flags of the GEMM beside it -- is
+ * only safe for a factorisation that has the card to itself, so it is used while ONE workspace has live plans in the process;
+ * from the second on every plan hands over in stream order (as option shared_card does unconditionally), and a plan whose
+ * launch sequence was recorded in the other mode records again at its next evaluation.  Returns 1 if evaluations of `p`
+ * enqueued now use the in-launch hand-over, 0 if not.  (gpmc_potrf_* called directly follow shared_card only: do not run them
+ * beside a plan's evaluation at look-ahead sizes without setting it.) */
+int gpmc_plan_handover_in_launch(const gpmc_plan* p);
 /* synchronises the plan's streams and releases the plan (its look-ahead stream, events and recorded launch graphs).
  * The stream passed to gpmc_plan_create must still be valid; the workspace is not touched. */
 int gpmc_plan_destroy(gpmc_plan* p);

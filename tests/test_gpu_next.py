@@ -245,6 +245,41 @@ def test_two_processes_share_one_card_at_full_size(n):
     assert d['config']['shared_card'] == 1, d['config']
 
 
+def test_plans_of_one_process_evaluate_concurrently_at_full_size():
+    """k independent chains on one card, one process: three plans at N = 8192, each on its own stream, each strictly
+    sequential, interleaved by the host.  With in-launch hand-overs this ran into the bounded wait (info = -1010025 with
+    two such plans; -1020026 with one of them beside another plan's tail launch): waiting workgroups of two factorisations
+    hold every CU slot and the GEMM they wait for cannot place a block.  The in-launch form is therefore used only while
+    one workspace has live plans (gpmc_plan_handover_in_launch); the others' appearance switches every plan to the
+    stream-ordered hand-over and makes it record again.  The values are those each plan gives alone, bit for bit."""
+    import gc
+    from gpmc import core
+    gc.collect()
+    n = 8192
+    hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [1.5, 9.0, 1.1]]
+    rng = np.random.RandomState(100)
+    first = core.LogMarginalPlan(rng.uniform(0, 10, (n, 2)), rng.standard_normal(n) * 5)
+    alone = [[first(h) for h in hyps]]
+    plans = [first]
+    for c in (1, 2):
+        rng = np.random.RandomState(100 + c)
+        plans.append(core.LogMarginalPlan(rng.uniform(0, 10, (n, 2)), rng.standard_normal(n) * 5))
+        alone.append([plans[-1](h) for h in hyps])
+    assert not any(p.handover_in_launch for p in plans)
+    for p in plans:
+        p.eval_async(hyps[0], 0)
+    for s in range(9):
+        for c, p in enumerate(plans):
+            got = p.result(0)[0]
+            assert got == alone[c][s % 3], (c, s, got, alone[c][s % 3])
+            p.eval_async(hyps[(s + 1) % 3], 0)
+    for p in plans:
+        p.result(0)
+    plans[1].close(), plans[2].close()
+    if first.handover_in_launch:       # (not if a plan of an earlier test is still alive)
+        assert first(hyps[1]) == alone[0][1]
+
+
 _NCCL_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'gaussianprocess-mcmc_amd'))
