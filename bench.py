@@ -286,7 +286,7 @@ def device_gp_draw(X, kernel, truth, seed):
     return g.cpu().numpy()
 
 
-def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
+def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy, chains=0):
     """One of BASELINE.json's other configs at its per-GPU size: ms per log-marginal evaluation (sync-each, like the
     headline), TF/s of N^3/3 and the fraction of the dtype's matrix peak.  f32: the same evaluation in f64 beside it and
     the stated tolerance |f32 - f64| <= 2e-4 |f64| asserted (tests/test_gpu_kernels.py::test_config5_shape_f32_vs_f64)."""
@@ -322,12 +322,44 @@ def time_config(name, n, d, kernel, dtype_name, steps, check_against_scipy):
     plan.drain()
     torch.cuda.synchronize()
     ms_pipe = 1e3 * (time.perf_counter() - t0) / npipe
+    multi = None
+    if chains > 1:
+        # `chains` independent chains on this one card, each strictly sequential (its next evaluation is enqueued when
+        # its previous result has been read), interleaved by this host thread: whole-card evaluations per second
+        others = [core.LogMarginalPlan(X, g, kernel, dtype=dt) for _ in range(chains - 1)]
+        for q in others:
+            for p in pts:
+                q(p)
+        ps = [plan] + others
+        for q in ps:
+            q(pts[0])                                                    # (plans alive together re-record: core.py)
+            q(pts[1])
+            q(pts[2])
+        torch.cuda.synchronize()
+        for q in ps:
+            q.eval_async(pts[0], 0)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            for q in ps:
+                r = q.result(0)
+                if r[3] != 0 or r[0] != vals[i % len(pts)]:
+                    raise SystemExit('%s: a concurrent chain returned %r, alone %r' % (name, r, vals[i % len(pts)]))
+                q.eval_async(pts[(i + 1) % len(pts)], 0)
+        for q in ps:
+            q.result(0)
+        dtc = time.perf_counter() - t0
+        multi = {'chains': chains, 'evals_per_s': steps * chains / dtc, 'ms_per_eval_per_chain': 1e3 * dtc / steps,
+                 'note': 'independent chains on ONE card, one process, each sync-each; values checked bit for bit against the single chain'}
+        for q in others:
+            q.close()
     plan.close()
     peak = 157.3 if dtype_name == 'f32' else FP64_MATRIX_PEAK_TF
     tf = n ** 3 / 3.0 / (ms * 1e-3) / 1e12
     out = {'name': name, 'workload': '%s, N=%d, d=%d, %s' % ('RBF' if kernel == 'rbf' else 'ARD Matern-5/2', n, d, dtype_name),
            'ms_per_eval': ms, 'evals_per_s': 1e3 / ms, 'steps': steps, 'tflops': tf, 'peak_tflops': peak, 'frac_of_peak': tf / peak,
            'enqueue': 'sync-each (result read before the next evaluation)', 'ms_per_eval_pipelined': ms_pipe}
+    if multi:
+        out['concurrent_chains'] = multi
     if dtype_name == 'f32':
         p64 = core.LogMarginalPlan(X, g, kernel, dtype=torch.float64, settle=False)
         v64 = [p64(p) for p in pts]
@@ -557,8 +589,8 @@ def main():
     if default_extras and a.n == 8192 and a.d == 2:
         # BASELINE.json's other configs at their per-GPU size, a few evaluations each (configs[1], configs[3] per GPU,
         # configs[4] per GPU)
-        timed = [time_config('n2048', 2048, 2, 'rbf', 'f64', 40, True),
-                 time_config('n4096', 4096, 2, 'rbf', 'f64', 30, True),
+        timed = [time_config('n2048', 2048, 2, 'rbf', 'f64', 40, True, chains=3),
+                 time_config('n4096', 4096, 2, 'rbf', 'f64', 30, True, chains=3),
                  time_config('n16384_f32', 16384, 8, 'matern52ard', 'f32', 6, False)]
         for _, chk in timed:
             if chk:
