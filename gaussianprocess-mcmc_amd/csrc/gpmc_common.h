@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../include/gpmc.h"
@@ -74,6 +75,7 @@ struct Options {
                               // process, ms/eval off / on): N = 5120 1.548 / 1.517, 6144 2.130 / 2.093, 7168 3.022 / 3.010,
                               // 8192 4.270 / 4.269 (its tail launch carries 8 history columns), <= 4096 +-0; in the look-ahead
                               // panels (8 columns, 32 workers per queue) beside the GEMM +0.8 %.  Off: nothing for the headline.
+    int kbuild_split = 1;     // a plan builds the first look-ahead panel's columns first and the rest of K beside that panel's factorisation
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);
                               // 0 = auto by the launch's bulk-to-chain ratio (potrf.hip, alone_workers: 256 - T, 256 or 480)
@@ -174,6 +176,13 @@ struct KbuildExtras {
     T* vec_dst = nullptr;
     int vec_n = 0;
     int* zero_word = nullptr;
+    // column range of this launch, in tiles of 128 columns: [ctile0, ctile1); ctile1 = 0: every column.  The log-marginal plan
+    // builds the first panel's columns first and the rest beside that panel's factorisation (plan.hip, Sched::after_fork).
+    int ctile0 = 0, ctile1 = 0;
+    // 16-byte words to clear (the factorisation's sync words: the fill launch in front of a tile-DAG launch rides here too),
+    // by the workgroups of the launch's first column of tiles
+    uint4* zero_ptr = nullptr;
+    unsigned zero_quads = 0;
 };
 template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
@@ -269,6 +278,14 @@ struct Sched {
 
     int init(hipStream_t main_stream);                       // creates the panel stream and a first batch of events
     int reserve_events(size_t n);
+    // The caller's matrix builder (optional): build_cols(stream, c0, c1) enqueues whatever writes columns [c0, c1) of the
+    // matrix (multiples of 128; all rows, riding rows included).  When it is set the caller has NOT built the matrix:
+    // potrf() calls it -- for everything before its first launch, or, where its schedule starts with a look-ahead panel on
+    // the second stream, for that panel's columns first and for the rest on the main stream BESIDE the panel's
+    // factorisation (the log-marginal plan's K build: 72 us at N = 8192, of which the first panel needs an eighth).
+    // (zero_ptr, zero_bytes: sync words potrf wants cleared before its first launch; the builder clears them in its own
+    // launch that holds column 0 -- no fill launch in front of the tile-DAG launch)
+    std::function<int(hipStream_t, int, int, void*, size_t)> build_cols;
     int edge_record(hipStream_t s, hipEvent_t* out);         // out = the event recorded on s
     int edge_wait(hipStream_t s, hipEvent_t e);
     int begin(int mode_);                                    // SEGMENTS / FORKJOIN: start capturing

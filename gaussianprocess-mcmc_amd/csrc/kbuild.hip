@@ -35,13 +35,17 @@ kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restric
               const T* __restrict__ hyp, T* __restrict__ K, int rows_out, int cols_out, int ldk, int flags,
               int same_xz, int vec_ok, KbuildExtras<T> ex) {
     const int row0 = blockIdx.y * KB_ROWS;
-    const int col0 = blockIdx.x * KB_COLS;
+    const int col0 = (blockIdx.x + ex.ctile0) * KB_COLS;
     // the log-marginal plan's per-evaluation housekeeping rides on workgroup (0, 0) instead of taking launches of its
     // own (a copy and a fill kernel of ~5 us each, 2 % of an N = 2048 evaluation): the right-hand side goes into its
     // riding row below the matrix, the factorisation's info word is cleared
     if (ex.vec_dst != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
         for (int e = threadIdx.x; e < ex.vec_n; e += 256) ex.vec_dst[e] = ex.vec_src[e];
         if (threadIdx.x == 0 && ex.zero_word != nullptr) *ex.zero_word = 0;
+    }
+    if (ex.zero_quads != 0 && blockIdx.x == 0) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (unsigned q = blockIdx.y * 256u + threadIdx.x; q < ex.zero_quads; q += gridDim.y * 256u) ex.zero_ptr[q] = z;
     }
     if ((flags & GPMC_KB_LOWER) && col0 > row0 + KB_ROWS - 1) return;  // tile strictly above the diagonal
 
@@ -138,7 +142,10 @@ int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, in
     GPMC_ARG(hyp_dev != nullptr && K != nullptr, 10);
     GPMC_ARG(rows_out >= n && cols_out >= nz && ldk >= cols_out, 11);
     const int vec_ok = (ldk % 2 == 0) && ((reinterpret_cast<uintptr_t>(K) % (2 * sizeof(T))) == 0);
-    dim3 grid((cols_out + KB_COLS - 1) / KB_COLS, (rows_out + KB_ROWS - 1) / KB_ROWS);
+    const int ctiles = (cols_out + KB_COLS - 1) / KB_COLS;
+    GPMC_ARG(ex.ctile0 >= 0 && ex.ctile1 >= 0 && ex.ctile1 <= ctiles && (ex.ctile1 == 0 || ex.ctile0 < ex.ctile1), 16);
+    if (ex.ctile1 == 0) { ex.ctile0 = 0; ex.ctile1 = ctiles; }
+    dim3 grid(ex.ctile1 - ex.ctile0, (rows_out + KB_ROWS - 1) / KB_ROWS);
     if (kernel == GPMC_KERNEL_RBF)
         hipLaunchKernelGGL((kbuild_kernel<T, GPMC_KERNEL_RBF>), grid, dim3(256), 0, s, X, n, d, ldx, Z, nz, ldz,
                            hyp_dev, K, rows_out, cols_out, ldk, flags, same, vec_ok, ex);

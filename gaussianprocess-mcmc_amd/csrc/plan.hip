@@ -102,12 +102,25 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
     ex.vec_dst = W + (size_t)L.np_ * L.ld;
     ex.vec_n = p->n;
     ex.zero_word = info;
-    int rc = kbuild<T>(p->kernel, X, p->n, p->d, p->d, nullptr, 0, 0, hyp, W, L.np_, L.np_, L.ld,
-                       GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, s, ex);
-    if (rc) return rc;
+    // potrf() calls the build itself (Sched::build_cols): all of K before its first launch, or -- where its schedule opens
+    // with a look-ahead panel on the second stream -- that panel's columns first and the rest beside its factorisation
+    gpmc_plan* const pp = p;
+    p->sched.build_cols = [=](hipStream_t st, int c0, int c1, void* zero_ptr, size_t zero_bytes) -> int {
+        KbuildExtras<T> e2;
+        if (c0 == 0) e2 = ex;          // g and the info word ride on the launch that holds tile (0, 0)
+        if (zero_bytes) {
+            e2.zero_ptr = reinterpret_cast<uint4*>(zero_ptr);
+            e2.zero_quads = (unsigned)(zero_bytes / 16);
+        }
+        e2.ctile0 = c0 / 128;
+        e2.ctile1 = (c1 + 127) / 128;
+        return kbuild<T>(pp->kernel, X, pp->n, pp->d, pp->d, nullptr, 0, 0, hyp, W, pp->L.np_, pp->L.np_, pp->L.ld,
+                         GPMC_KB_LOWER | GPMC_KB_PAD_IDENTITY, st, e2);
+    };
     p->sched.info_cleared = true;
-    rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched, 1);      // one riding row: g
+    int rc = potrf<T>(W, L.mp, L.np_, L.ld, info, p->ws + L.off_scratch, s, 0, &p->sched, 1);      // one riding row: g
     p->sched.info_cleared = false;
+    p->sched.build_cols = nullptr;
     if (rc) return rc;
     return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s, p->host_res_dev, hyp + (2 + PLAN_MAXD));
 }
@@ -207,6 +220,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "dag_wprio")) g_opt.dag_wprio = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
+    else if (!strcmp(name, "kbuild_split")) g_opt.kbuild_split = value ? 1 : 0;
     else if (!strcmp(name, "tail_xcd")) g_opt.tail_xcd = value ? 1 : 0;
     else if (!strcmp(name, "tail_skip")) g_opt.tail_skip = value & 3;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
@@ -259,6 +273,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "dag_wprio")) return g_opt.dag_wprio;
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
+    if (!strcmp(name, "kbuild_split")) return g_opt.kbuild_split;
     if (!strcmp(name, "tail_xcd")) return g_opt.tail_xcd;
     if (!strcmp(name, "tail_skip")) return g_opt.tail_skip;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;

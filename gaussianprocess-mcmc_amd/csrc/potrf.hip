@@ -778,6 +778,23 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         return dag_launch(k0, (np_ - k0) / NB_IN, mp, 0, s, alone_workers(k0, (np_ - k0) / NB_IN, mp, 0));
     };
     if (g_opt.lookahead < 0 && use_tail(0)) la = false;      // the whole problem is one tile-DAG launch
+    // the caller's matrix builder (Sched::build_cols): everything now, unless the schedule starts with a tile-DAG panel on
+    // the second stream -- then that panel's columns first and the rest beside its factorisation (below)
+    const bool dag_la = la && np_ > NB && tail_ok && g_opt.la_dag && sizeof(T) == 8;
+    const bool have_builder = sc && sc->build_cols;
+    auto build_cols = [&](int c0, int c1, void* zp = nullptr, size_t zb = 0) -> int {
+        if (!have_builder || c0 >= c1) return 0;
+        return sc->build_cols(s, c0, c1, zp, zb);
+    };
+    if (!dag_la || !g_opt.kbuild_split) {
+        // (a problem that is ONE tile-DAG launch: its sync words are cleared by the builder's launch, not by a fill launch)
+        size_t zb = 0;
+        if (have_builder && !la && use_tail(0))
+            zb = (tail_sync_words(np_ / NB_IN, mp / NB_IN) * sizeof(unsigned) + 15) & ~(size_t)15;
+        int rcb = build_cols(0, np_, zb ? dag_sync : nullptr, zb);
+        if (rcb) return rcb;
+        if (zb) sync_zeroed = true;
+    }
     // look-ahead hands over to the tail once the tile-DAG launch can take the rest (else: once < la_min_m columns remain)
     auto hand_over = [&](int k1) { return tail_ok ? use_tail(k1) : (np_ - k1 < g_opt.la_min_m); };
     // serial schedule from column kstart on (the panel at kstart is factored first), outer block nbs
@@ -877,12 +894,16 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 total += handover_words(k1, k1 + nb);
                 k0 = k1;
             }
-            if (total * sizeof(unsigned) <= TAIL_SYNC_BYTES) {
-                const size_t zb = (total * sizeof(unsigned) + 15) & ~(size_t)15;
+            const bool fits = total * sizeof(unsigned) <= TAIL_SYNC_BYTES;
+            const size_t zb = fits ? ((total * sizeof(unsigned) + 15) & ~(size_t)15) : 0;
+            if (have_builder && g_opt.kbuild_split) {      // the first panel's columns, and the sync words with them
+                int rcb = build_cols(0, nbk, zb ? dag_sync : nullptr, zb);
+                if (rcb) return rcb;
+            } else if (fits) {
                 int rcz = zero_words(dag_sync, zb, nullptr, s);
                 if (rcz) return rcz;
-                sync_zeroed = true;
             }
+            sync_zeroed = fits;
         }
         {
             hipEvent_t ef;
@@ -894,6 +915,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
             if (rc) return rc;
             rc = sc->edge_record(ps, &pe);
             if (rc) return rc;
+            if (g_opt.kbuild_split && have_builder && nbk < np_) {      // the rest of the caller's matrix, on s, beside D_0
+                rc = build_cols(nbk, np_);
+                if (rc) return rc;
+                // D_1 reads its own columns' start values: it is enqueued behind D_0 on ps and, through this edge, behind
+                // the rest of the build on s (every later panel launch waits for a GEMM that follows the build on s)
+                rc = sc->edge_record(s, &ge);
+                if (rc) return rc;
+            }
         }
         for (int k0 = 0;;) {
             const int k1 = k0 + nbk;

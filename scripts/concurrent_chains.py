@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """k independent chains on ONE GPU, each strictly sequential (the next evaluation of a chain is enqueued only after its
 previous result has been read, as the sampler must), interleaved by one host thread: whole-GPU evaluations per second.
-usage: python3 scripts/concurrent_chains.py N k[,k...]"""
+usage: python3 scripts/concurrent_chains.py N k[,k...] [option=value ...]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.join(ROOT, 'gaussianprocess-mcmc_amd'))
 import gpmc
 from gpmc import core
 n = int(sys.argv[1]); ks = [int(v) for v in sys.argv[2].split(',')]
+for kv in sys.argv[3:]:                                  # options: name=value
+    gpmc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [1.5, 9.0, 1.1]]
 plans = []
 for c in range(max(ks)):

@@ -175,15 +175,16 @@ def test_tile_dag_schedule_knobs_do_not_change_the_bits(gp):
     at a one-launch size (4200) and a two-stream size (7300)."""
     gpmc = gp['gpmc']
     reset = {'tail_park': 1, 'tail_warm': 1, 'tail_workers': 0, 'dag_workers': 0, 'outer_nb': 0, 'dag_ahead': 1,
-             'tail_m': 6144, 'tail_acc16': 1, 'tail_prefetch_t': 72, 'dag_prefetch': 0, 'tail_xcd': 0, 'tail_skip': 3}
+             'tail_m': 6144, 'tail_acc16': 1, 'tail_prefetch_t': 72, 'dag_prefetch': 0, 'tail_xcd': 0, 'tail_skip': 3, 'kbuild_split': 1}
     # (tail_acc16 = 0: the v_mfma_f64_4x4x4 form of the accumulation -- another instruction, the same sums;
     #  tail_prefetch_t = 1 / 0: every / no launch prefetches the next column's operand tiles; tail_xcd: worker tickets in eight
-    #  queues by column, served XCD by XCD, or in one; tail_skip: the unused half of the one-row riding block left out or not)
+    #  queues by column, served XCD by XCD, or in one; tail_skip: the unused half of the one-row riding block left out or not;
+    #  kbuild_split = 0: all of K is built before the first panel instead of the rest of it beside that panel)
     for n, variants in ((4200, [{}, {'tail_park': 0}, {'tail_warm': 0}, {'tail_workers': 96}, {'tail_workers': 480}, {'tail_acc16': 0},
                                 {'tail_prefetch_t': 1}, {'tail_xcd': 1}, {'tail_skip': 0}, {'tail_skip': 1, 'tail_xcd': 1, 'tail_workers': 480}]),
                         (7300, [{}, {'tail_park': 0}, {'tail_warm': 0}, {'dag_workers': 64}, {'outer_nb': 256}, {'outer_nb': 512},
                                 {'dag_ahead': 0}, {'tail_m': 4096}, {'tail_acc16': 0}, {'tail_prefetch_t': 0},
-                                {'tail_prefetch_t': 1, 'dag_prefetch': 1}, {'outer_nb': 384}, {'tail_xcd': 1}, {'tail_skip': 0},
+                                {'tail_prefetch_t': 1, 'dag_prefetch': 1}, {'outer_nb': 384}, {'tail_xcd': 1}, {'tail_skip': 0}, {'kbuild_split': 0}, {'kbuild_split': 0, 'outer_nb': 256},
                                 {'tail_xcd': 1, 'dag_ahead': 0, 'dag_workers': 48}])):
         x, g = _x(n, 2, 31), np.random.RandomState(32).standard_normal(n) * 5.
         vals = []
