@@ -164,6 +164,7 @@ size_t potrf_scratch_bytes(int np_);
 // set around a factorisation whose launches must not wait for one another inside the kernels (plan.hip: every plan but
 // the process's one hand-over owner): the look-ahead hand-over is then the stream-ordered one, as with shared_card
 extern bool g_ordered_handover;
+constexpr int GPMC_RING_OUT_OF_STEP = -3000001;   // *info of a plan evaluation whose parameter block belongs to another execution
 extern unsigned long long* g_tail_dbg;   // diagnostic stamp buffer of the tail kernel (nullptr in production)
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -183,6 +184,10 @@ struct KbuildExtras {
     // by the workgroups of the launch's first column of tiles
     uint4* zero_ptr = nullptr;
     unsigned zero_quads = 0;
+    // parameter ring (log-marginal plans): hyp_dev is then the base of a ring of 64 parameter blocks of ring_stride elements
+    // in pinned, device-mapped HOST memory, and this launch reads block (*seq & 63) -- no host-to-device copy per evaluation
+    const unsigned* seq = nullptr;
+    int ring_stride = 0;
 };
 template <typename T>
 int kbuild(int kernel, const T* X, int n, int d, int ldx, const T* Z, int nz, int ldz, const T* hyp_dev, T* K,
@@ -195,7 +200,7 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
 // host_base + 4 * (int)*slot_dev, so that no copy has to follow the reduction
 template <typename T>
 int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s,
-                double* host_base = nullptr, const T* slot_dev = nullptr);
+                double* host_base = nullptr, const T* slot_dev = nullptr, unsigned* seq = nullptr, int ring_stride = 0);
 template <typename T>
 int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s);
 template <typename T>

@@ -32,8 +32,9 @@ __device__ inline float dev_sqrt<float>(float x) { return sqrtf(x); }
 template <typename T, int KERNEL>
 __global__ void __launch_bounds__(256)
 kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restrict__ Z, int nz, int ldz,
-              const T* __restrict__ hyp, T* __restrict__ K, int rows_out, int cols_out, int ldk, int flags,
+              const T* __restrict__ hyp_in, T* __restrict__ K, int rows_out, int cols_out, int ldk, int flags,
               int same_xz, int vec_ok, KbuildExtras<T> ex) {
+    const T* hyp = hyp_in;
     const int row0 = blockIdx.y * KB_ROWS;
     const int col0 = (blockIdx.x + ex.ctile0) * KB_COLS;
     // the log-marginal plan's per-evaluation housekeeping rides on workgroup (0, 0) instead of taking launches of its
@@ -56,8 +57,19 @@ kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restric
     const int tx = tid & 63;
     const int w = tid >> 6;
     const bool ard = (KERNEL == GPMC_KERNEL_MATERN52_ARD);
-    const T sf2 = hyp[0];
-    const T dadd = hyp[1];
+    // the parameters once into LDS: with a parameter ring (ex.seq) they sit in host memory, and every read of hyp[] in the
+    // staging loops below would be a PCIe round trip
+    __shared__ T hs[2 + 64];
+    const int nh = 2 + (ard ? d : 1);
+    const bool hyp_staged = nh <= 2 + 64;
+    if (ex.seq != nullptr) hyp += (size_t)(*ex.seq & 63u) * ex.ring_stride;
+    if (hyp_staged) {
+        if (tid < nh) hs[tid] = hyp[tid];
+        __syncthreads();
+    }
+    auto H = [&](int k) -> T { return hyp_staged ? hs[k] : hyp[k]; };
+    const T sf2 = H(0);
+    const T dadd = H(1);
 
     T acc0[KB_RPT], acc1[KB_RPT];
 #pragma unroll
@@ -70,13 +82,13 @@ kbuild_kernel(const T* __restrict__ X, int n, int d, int ldx, const T* __restric
         for (int e = tid; e < KB_ROWS * KB_DC; e += 256) {
             const int r = e / KB_DC, kk = e % KB_DC;
             T v = 0;
-            if (kk < kc && row0 + r < n) v = X[(size_t)(row0 + r) * ldx + k0 + kk] / hyp[2 + (ard ? k0 + kk : 0)];
+            if (kk < kc && row0 + r < n) v = X[(size_t)(row0 + r) * ldx + k0 + kk] / H(2 + (ard ? k0 + kk : 0));
             xi[r][kk] = v;
         }
         for (int e = tid; e < KB_COLS * KB_DC; e += 256) {
             const int c = e / KB_DC, kk = e % KB_DC;
             T v = 0;
-            if (kk < kc && col0 + c < nz) v = Z[(size_t)(col0 + c) * ldz + k0 + kk] / hyp[2 + (ard ? k0 + kk : 0)];
+            if (kk < kc && col0 + c < nz) v = Z[(size_t)(col0 + c) * ldz + k0 + kk] / H(2 + (ard ? k0 + kk : 0));
             xj[kk][c] = v;
         }
         __syncthreads();

@@ -35,7 +35,7 @@ static PlanLayout plan_layout(int n, int d, int es) {
     L.off_W = take((size_t)L.mp * L.ld * es);
     L.off_X = take((size_t)n * d * es);
     L.off_g = take((size_t)n * es);
-    L.off_hyp = take((size_t)(2 + PLAN_MAXD + 1) * es);      // parameters + the result slot's index
+    L.off_hyp = take((size_t)(2 + PLAN_MAXD + 2) * es);      // (round 1-3a: the device copy of the parameter block; unused since the ring)
     L.off_out = take(4 * sizeof(double));
     L.off_info = take(sizeof(int));
     L.off_scratch = take(potrf_scratch_bytes(L.np_));
@@ -53,6 +53,15 @@ struct gpmc_plan {
     double* host_pin;     // PLAN_SLOTS x (2+MAXD) staged parameters (as T bytes) + PLAN_SLOTS x 4 results
     size_t hyp_slot_bytes;
     double* host_res_dev; // device address of the pinned results (PLAN_SLOTS x 4 doubles)
+    // Parameter ring: the staged parameters are never copied to the device.  Every EXECUTION of the launch sequence (eager,
+    // replay, a recording attempt) reads block (seq & 63) of the pinned ring through its device mapping and its reduction
+    // moves seq on; the host writes the block for execution number `execs` before it launches it.  At most 64 evaluations
+    // are in flight (each holds a result slot), so a block is rewritten only after its execution has finished.
+    void* ring_dev;       // device address of host_pin
+    unsigned* seq_dev;    // device word: executions completed (its own small allocation: plans may share a workspace)
+    unsigned execs;       // executions launched
+    bool resync;          // an execution may have been launched in part: set seq = execs before the next one
+    char cur_stage[(2 + 62 + 2) * sizeof(double)];   // the current evaluation's parameter block (as T bytes) + slot index + execution number
     gpmc::Sched sched;    // the plan's own panel stream, events and recorded launch sequence
     bool recorded;
     hipEvent_t ev0, ev1;  // timing of the eager first evaluation and of the first replay (see record_sequence)
@@ -92,7 +101,8 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
     T* W = reinterpret_cast<T*>(p->ws + L.off_W);
     const T* X = reinterpret_cast<const T*>(p->ws + L.off_X);
     const T* g = reinterpret_cast<const T*>(p->ws + L.off_g);
-    const T* hyp = reinterpret_cast<const T*>(p->ws + L.off_hyp);
+    const T* hyp = reinterpret_cast<const T*>(p->ring_dev);     // ring base (pinned host memory): block (*seq & 63)
+    constexpr int RING_STRIDE = 2 + PLAN_MAXD + 2;
     double* out = reinterpret_cast<double*>(p->ws + L.off_out);
     int* info = reinterpret_cast<int*>(p->ws + L.off_info);
     // the kernel build also puts g into its riding row and clears info (no copy / fill launches of their own), and the
@@ -102,12 +112,16 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
     ex.vec_dst = W + (size_t)L.np_ * L.ld;
     ex.vec_n = p->n;
     ex.zero_word = info;
+    ex.seq = p->seq_dev;
+    ex.ring_stride = RING_STRIDE;
     // potrf() calls the build itself (Sched::build_cols): all of K before its first launch, or -- where its schedule opens
     // with a look-ahead panel on the second stream -- that panel's columns first and the rest beside its factorisation
     gpmc_plan* const pp = p;
     p->sched.build_cols = [=](hipStream_t st, int c0, int c1, void* zero_ptr, size_t zero_bytes) -> int {
         KbuildExtras<T> e2;
         if (c0 == 0) e2 = ex;          // g and the info word ride on the launch that holds tile (0, 0)
+        e2.seq = ex.seq;
+        e2.ring_stride = ex.ring_stride;
         if (zero_bytes) {
             e2.zero_ptr = reinterpret_cast<uint4*>(zero_ptr);
             e2.zero_quads = (unsigned)(zero_bytes / 16);
@@ -122,7 +136,8 @@ static int plan_enqueue_body(gpmc_plan* p, hipStream_t s) {
     p->sched.info_cleared = false;
     p->sched.build_cols = nullptr;
     if (rc) return rc;
-    return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s, p->host_res_dev, hyp + (2 + PLAN_MAXD));
+    return logdet_quad<T>(W, p->n, L.ld, W + (size_t)L.np_ * L.ld, info, out, s, p->host_res_dev, hyp + (2 + PLAN_MAXD),
+                          p->seq_dev, RING_STRIDE);
 }
 
 static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
@@ -139,6 +154,17 @@ static int plan_enqueue(gpmc_plan* p, hipStream_t s) {
 // yardstick is the plan's SECOND eager evaluation (the first also pays hipFuncSetAttribute, code-object loads and cold
 // host launch paths, which let a +12 % exec through).  One-stream schedules have nothing to alias: they are recorded
 // once and never timed against anything.
+// the parameter block of the execution about to be launched (see gpmc_plan: parameter ring)
+static void stage_params(gpmc_plan* p) {
+    const size_t bytes = (size_t)(2 + PLAN_MAXD + 2) * p->es;
+    // the block carries its execution number (mod 2^20: exact in float too); the reduction compares it with the device's
+    // sequence number and reports GPMC_RING_OUT_OF_STEP instead of a result if they ever differ
+    if (p->es == 8) reinterpret_cast<double*>(p->cur_stage)[2 + PLAN_MAXD + 1] = (double)(p->execs & 0xfffffu);
+    else reinterpret_cast<float*>(p->cur_stage)[2 + PLAN_MAXD + 1] = (float)(p->execs & 0xfffffu);
+    memcpy(reinterpret_cast<char*>(p->host_pin) + (size_t)(p->execs & 63u) * bytes, p->cur_stage, bytes);
+    p->execs++;
+}
+
 static int record_sequence(gpmc_plan* p) {
     // (a plan whose eager evaluations ran while use_graph was off has no yardstick: its first recording is accepted)
     const bool have_yardstick = p->ev0 != nullptr && p->eager_ms > 0.f;
@@ -153,6 +179,7 @@ static int record_sequence(gpmc_plan* p) {
         const int rc2 = p->sched.end();
         if (rc || rc2) { (void)p->sched.drop_ops(); return rc ? rc : rc2; }
         GPMC_HIP(hipEventRecord(p->ev0, p->stream));
+        stage_params(p);
         rc = p->sched.replay();
         if (rc) return rc;
         GPMC_HIP(hipEventRecord(p->ev1, p->stream));
@@ -467,6 +494,8 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     p->stream = S_(stream);
     p->recorded = false; p->evals = 0; p->have_data = false;
     p->ordered = false;
+    p->ring_dev = nullptr; p->seq_dev = nullptr; p->execs = 0; p->resync = false;
+    memset(p->cur_stage, 0, sizeof(p->cur_stage));
     p->ev0 = p->ev1 = nullptr; p->eager_ms = p->replay_ms = 0.f; p->record_attempts = 0; p->recorded_form = -1;
     memset(p->slot_busy, 0, sizeof(p->slot_busy));
     memset(p->slot_ev, 0, sizeof(p->slot_ev));
@@ -476,7 +505,7 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
         if (!rc) rc = p->sched.reserve_events((size_t)(2 * (L.np_ / GPMC_PAD) + 8));
         if (rc) { (void)p->sched.destroy(); delete p; return rc; }
     }
-    p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD + 1) * sizeof(double);
+    p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD + 2) * sizeof(double);
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p->host_pin),
                                  PLAN_SLOTS * (p->hyp_slot_bytes + 4 * sizeof(double)), hipHostMallocDefault);
     if (e != hipSuccess) { (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -485,11 +514,18 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
         e = hipHostGetDevicePointer(&dres, reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes, 0);
         if (e != hipSuccess) { (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
         p->host_res_dev = reinterpret_cast<double*>(dres);
+        e = hipHostGetDevicePointer(&dres, p->host_pin, 0);
+        if (e == hipSuccess) {
+            p->ring_dev = dres;
+            e = hipMalloc(reinterpret_cast<void**>(&p->seq_dev), 256);
+            if (e == hipSuccess) e = hipMemsetAsync(p->seq_dev, 0, 256, p->stream);
+        }
+        if (e != hipSuccess) { if (p->seq_dev) (void)hipFree(p->seq_dev); (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "parameter ring: %s", hipGetErrorString(e)); }
     }
     // zero the riding rows once: only row np_ is ever rewritten (with g), the others stay zero
     e = hipMemsetAsync(p->ws + L.off_W + (size_t)L.np_ * L.ld * elem_size, 0,
                        (size_t)(L.mp - L.np_) * L.ld * elem_size, p->stream);
-    if (e != hipSuccess) { (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(p->seq_dev); (void)hipHostFree(p->host_pin); (void)p->sched.destroy(); delete p; return fail((int)e, "hipMemsetAsync: %s", hipGetErrorString(e)); }
     ++g_live_ws[p->ws];
     p->ordered = plans_must_order();
     *out = p;
@@ -512,23 +548,28 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     const int need = 2 + (p->kernel == GPMC_KERNEL_RBF ? 1 : p->d);
     GPMC_ARG(kparams_host != nullptr && nk == need, 3);
     GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 4);
-    // a slot's pinned staging feeds an asynchronous H2D copy and its result lands asynchronously: re-arming it while
-    // its evaluation is still in flight would silently run the earlier evaluation with the later parameters
+    // a slot's result lands asynchronously, and the number of busy slots bounds the executions in flight, which is what keeps
+    // the parameter ring's blocks from being rewritten under a running evaluation
     if (p->slot_busy[slot])
         return fail(-4, "gpmc_plan_logml_async: slot %d still has an evaluation in flight (call gpmc_plan_result first)", slot);
-    char* hslot = reinterpret_cast<char*>(p->host_pin) + (size_t)slot * p->hyp_slot_bytes;
     // staged: the parameters, then (at element 2 + PLAN_MAXD) the index of the result slot, which the reduction kernel
-    // reads back to find where in pinned memory this evaluation's result belongs -- ONE copy carries both
+    // reads back to find where in pinned memory this evaluation's result belongs
     if (p->es == 8) {
-        double* d = reinterpret_cast<double*>(hslot);
+        double* d = reinterpret_cast<double*>(p->cur_stage);
         memcpy(d, kparams_host, (size_t)nk * sizeof(double));
         d[2 + PLAN_MAXD] = (double)slot;
     } else {
-        float* f = reinterpret_cast<float*>(hslot);
+        float* f = reinterpret_cast<float*>(p->cur_stage);
         for (int i = 0; i < nk; ++i) f[i] = (float)kparams_host[i];
         f[2 + PLAN_MAXD] = (float)slot;
     }
     int rc = 0;
+    if (p->resync) {      // an earlier execution failed part-way: executions launched and executions completed must agree
+        GPMC_HIP(hipStreamSynchronize(p->stream));
+        if (p->sched.panel) GPMC_HIP(hipStreamSynchronize(p->sched.panel));
+        GPMC_HIP(hipMemcpy(p->seq_dev, &p->execs, sizeof(unsigned), hipMemcpyHostToDevice));
+        p->resync = false;
+    }
     if (p->ordered != plans_must_order()) {
         // another plan appeared (or the last other one went): the sequence recorded in the old mode is retired and this plan
         // starts over -- two eager evaluations (the second one the yardstick), then a new recording
@@ -542,7 +583,6 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
         p->evals = 0;
         p->ordered = plans_must_order();
     }
-    GPMC_HIP(hipMemcpyAsync(p->ws + p->L.off_hyp, hslot, (size_t)(2 + PLAN_MAXD + 1) * p->es, hipMemcpyHostToDevice, p->stream));
     const bool graph_ok = g_opt.use_graph && p->stream != nullptr;   // the NULL stream cannot be captured
     if (!graph_ok || p->evals < 2) {
         // eager launches: the first evaluation always (it sets the kernels' attributes, which a capture would record);
@@ -553,19 +593,21 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
             GPMC_HIP(hipEventRecord(p->ev0, p->stream));
         }
         p->sched.mode = Sched::EAGER;
+        stage_params(p);
         rc = plan_enqueue(p, p->stream);
-        if (rc) return rc;
+        if (rc) { p->resync = true; return rc; }
         if (timeit) {
             GPMC_HIP(hipEventRecord(p->ev1, p->stream));
             GPMC_HIP(hipEventSynchronize(p->ev1));
             GPMC_HIP(hipEventElapsedTime(&p->eager_ms, p->ev0, p->ev1));
         }
     } else if (p->recorded) {
+        stage_params(p);
         rc = p->sched.replay();
-        if (rc) return rc;
+        if (rc) { p->resync = true; return rc; }
     } else {
         rc = record_sequence(p);      // records AND replays once (a real evaluation of the current parameters)
-        if (rc) return rc;
+        if (rc) { p->resync = true; return rc; }
     }
     p->evals++;
     p->slot_busy[slot] = 1;
@@ -586,6 +628,7 @@ int gpmc_debug_graph_churn(gpmc_plan* p, int form, int device_sync, int iters) {
     GPMC_HIP(hipStreamSynchronize(p->stream));
     (void)p->sched.drop_ops();
     p->recorded = false;
+    p->resync = true;     // (the executions below consume sequence numbers without parameter blocks of their own)
     for (int i = 0; i < iters; ++i) {
         int rc = p->sched.begin(form ? Sched::FORKJOIN : Sched::SEGMENTS);
         if (rc) return rc;
@@ -632,6 +675,11 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host) {
     }
     const double* hres = reinterpret_cast<const double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
     for (int i = 0; i < 4; ++i) out_host[i] = hres[i];
+    if (out_host[3] == (double)GPMC_RING_OUT_OF_STEP) {
+        p->resync = true;
+        return fail(-6, "gpmc_plan_result: the evaluation read the parameter block of another execution (host and device "
+                        "sequence numbers differ); the next evaluation resynchronises -- repeat this one");
+    }
     return 0;
 }
 
@@ -658,6 +706,7 @@ int gpmc_plan_destroy(gpmc_plan* p) {
     for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
     if (p->ev0) { (void)hipEventDestroy(p->ev0); (void)hipEventDestroy(p->ev1); }
     if (p->host_pin) (void)hipHostFree(p->host_pin);
+    if (p->seq_dev) (void)hipFree(p->seq_dev);
     delete p;
     return 0;
 }

@@ -10,7 +10,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024)
 logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict__ alpha,
                    const int* __restrict__ info, double* __restrict__ out, double* __restrict__ host_base,
-                   const T* __restrict__ slot_dev) {
+                   const T* __restrict__ slot_dev, unsigned* __restrict__ seq, int ring_stride) {
     __shared__ double s_ld[1024], s_q[1024];
     const int tid = threadIdx.x;
     double ld = 0.0, qd = 0.0;
@@ -36,21 +36,29 @@ logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict_
         out[2] = s_q[0];
         out[3] = info ? (double)info[0] : 0.0;
         if (host_base != nullptr) {      // pinned, device-mapped: visible to the host once this kernel has completed
-            double* h = host_base + 4 * (int)slot_dev[0];
+            // (with a parameter ring the slot index sits in block (*seq & 63) of the ring, and this evaluation -- the ring
+            //  block's last reader -- moves the sequence number on)
+            const unsigned k = seq ? *seq : 0u;
+            const T* blk = slot_dev + (size_t)(k & 63u) * ring_stride;
+            double* h = host_base + 4 * (int)blk[0];
+            // (the block names the execution it was written for, right behind the slot index: a block of another execution
+            //  means host and device lost step, and the host gets that instead of a value computed from the wrong parameters)
+            if (seq && (unsigned)blk[1] != (k & 0xfffffu)) out[3] = (double)GPMC_RING_OUT_OF_STEP;
             for (int j = 0; j < 4; ++j) h[j] = out[j];
             __threadfence_system();
+            if (seq) *seq = k + 1u;
         }
     }
 }
 
 template <typename T>
 int logdet_quad(const T* W, int n, int ldw, const T* alpha, const int* info_dev, double* out_dev, hipStream_t s,
-                double* host_base, const T* slot_dev) {
+                double* host_base, const T* slot_dev, unsigned* seq, int ring_stride) {
     GPMC_ARG(W && n > 0 && ldw >= n, 1);
     GPMC_ARG(alpha != nullptr, 4);
     GPMC_ARG(out_dev != nullptr, 6);
     hipLaunchKernelGGL((logdet_quad_kernel<T>), dim3(1), dim3(1024), 0, s, W, n, ldw, alpha, info_dev, out_dev,
-                       (host_base != nullptr && slot_dev != nullptr) ? host_base : nullptr, slot_dev);
+                       (host_base != nullptr && slot_dev != nullptr) ? host_base : nullptr, slot_dev, seq, ring_stride);
     GPMC_LAUNCH_CHECK();
     return 0;
 }
@@ -294,7 +302,7 @@ int trmv_lower(const T* W, int n, int ldw, const T* x, const T* y0, T* y, hipStr
 }
 
 #define INST(T)                                                                                              \
-    template int logdet_quad<T>(const T*, int, int, const T*, const int*, double*, hipStream_t, double*, const T*);             \
+    template int logdet_quad<T>(const T*, int, int, const T*, const int*, double*, hipStream_t, double*, const T*, unsigned*, int);             \
     template int pack_lower<T>(const T*, int, int, T, T*, int, int, hipStream_t);                            \
     template int pack_rows<T>(const T*, int, int, int, T*, int, int, int, hipStream_t);                      \
     template int unpack_lower<T>(const T*, int, int, T*, int, int, hipStream_t);                             \

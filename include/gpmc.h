@@ -232,9 +232,12 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
                      size_t workspace_bytes, gpmc_stream_t stream);
 /* X: n x d host or device row-major (copied into the workspace), g: n elements */
 int gpmc_plan_set_data(gpmc_plan* p, const void* X_dev, int ldx, const void* g_dev);
-/* asynchronous: enqueue one evaluation; the result lands in host result slot `slot` (0..63).  A slot also owns the
- * pinned staging of its parameters: re-arming a slot whose evaluation has not been read back with gpmc_plan_result
- * returns -4 (nothing is enqueued).
+/* asynchronous: enqueue one evaluation; the result lands in host result slot `slot` (0..63).  Re-arming a slot whose
+ * evaluation has not been read back with gpmc_plan_result returns -4 (nothing is enqueued).  The parameters are not
+ * copied to the device: they are written into a ring of 64 blocks in pinned host memory, and the evaluation's kernels
+ * read block (sequence number mod 64) through its device mapping (the reduction moves the device's sequence number on;
+ * a block that names another execution makes gpmc_plan_result return -6 instead of a value -- it cannot happen
+ * unless an enqueue failed part-way, after which the next call resynchronises).
  * kparams_host = kernel-ready parameters in gpmc_kbuild's hyp layout, as doubles: [sf^2, S_ii, ell...]
  * (nk = 3 for RBF, 2 + d for ARD) -- the caller forms them from the sampler's (ell, sf, sn) exactly as the
  * reference does: exp(log .) round trips and the S_ii expression of sliceSample.py:184-187. */
