@@ -75,6 +75,7 @@ struct Options {
                               // process, ms/eval off / on): N = 5120 1.548 / 1.517, 6144 2.130 / 2.093, 7168 3.022 / 3.010,
                               // 8192 4.270 / 4.269 (its tail launch carries 8 history columns), <= 4096 +-0; in the look-ahead
                               // panels (8 columns, 32 workers per queue) beside the GEMM +0.8 %.  Off: nothing for the headline.
+    int result_poll_us = 20000;   // gpmc_plan_result polls the result's stamp in pinned memory for up to this long before it waits on the event (0: event only)
     int kbuild_split = 1;     // a plan builds the first look-ahead panel's columns first and the rest of K beside that panel's factorisation
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);

@@ -13,6 +13,8 @@
 #include <new>
 
 #include "gpmc_common.h"
+#include <atomic>
+#include <chrono>
 #include <map>
 
 namespace gpmc {
@@ -60,6 +62,7 @@ struct gpmc_plan {
     void* ring_dev;       // device address of host_pin
     unsigned* seq_dev;    // device word: executions completed (its own small allocation: plans may share a workspace)
     unsigned execs;       // executions launched
+    unsigned slot_exec[64];   // the execution whose result a busy slot waits for (its number mod 2^20 is the slot's stamp)
     bool resync;          // an execution may have been launched in part: set seq = execs before the next one
     char cur_stage[(2 + 62 + 2) * sizeof(double)];   // the current evaluation's parameter block (as T bytes) + slot index + execution number
     gpmc::Sched sched;    // the plan's own panel stream, events and recorded launch sequence
@@ -248,6 +251,7 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
     else if (!strcmp(name, "kbuild_split")) g_opt.kbuild_split = value ? 1 : 0;
+    else if (!strcmp(name, "result_poll_us")) g_opt.result_poll_us = value < 0 ? 0 : value;
     else if (!strcmp(name, "tail_xcd")) g_opt.tail_xcd = value ? 1 : 0;
     else if (!strcmp(name, "tail_skip")) g_opt.tail_skip = value & 3;
     else if (!strcmp(name, "tail_acc16")) g_opt.tail_acc16 = value ? 1 : 0;
@@ -301,6 +305,7 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
     if (!strcmp(name, "kbuild_split")) return g_opt.kbuild_split;
+    if (!strcmp(name, "result_poll_us")) return g_opt.result_poll_us;
     if (!strcmp(name, "tail_xcd")) return g_opt.tail_xcd;
     if (!strcmp(name, "tail_skip")) return g_opt.tail_skip;
     if (!strcmp(name, "tail_acc16")) return g_opt.tail_acc16;
@@ -507,8 +512,10 @@ int gpmc_plan_create(gpmc_plan** out, int kernel, int n, int d, int elem_size, v
     }
     p->hyp_slot_bytes = (size_t)(2 + PLAN_MAXD + 2) * sizeof(double);
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p->host_pin),
-                                 PLAN_SLOTS * (p->hyp_slot_bytes + 4 * sizeof(double)), hipHostMallocDefault);
+                                 PLAN_SLOTS * (p->hyp_slot_bytes + 5 * sizeof(double)), hipHostMallocDefault);
     if (e != hipSuccess) { (void)p->sched.destroy(); delete p; return fail((int)e, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < PLAN_SLOTS; ++i)      // result stamps: no execution yet
+        (reinterpret_cast<double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes))[4 * PLAN_SLOTS + i] = -1.0;
     {   // the reduction kernel writes each result straight into its pinned slot
         void* dres = nullptr;
         e = hipHostGetDevicePointer(&dres, reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes, 0);
@@ -552,6 +559,7 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     // the parameter ring's blocks from being rewritten under a running evaluation
     if (p->slot_busy[slot])
         return fail(-4, "gpmc_plan_logml_async: slot %d still has an evaluation in flight (call gpmc_plan_result first)", slot);
+    (reinterpret_cast<double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes))[4 * PLAN_SLOTS + slot] = -1.0;   // the slot's stamp: no result yet
     // staged: the parameters, then (at element 2 + PLAN_MAXD) the index of the result slot, which the reduction kernel
     // reads back to find where in pinned memory this evaluation's result belongs
     if (p->es == 8) {
@@ -611,6 +619,7 @@ int gpmc_plan_logml_async(gpmc_plan* p, const double* kparams_host, int nk, int 
     }
     p->evals++;
     p->slot_busy[slot] = 1;
+    p->slot_exec[slot] = (p->execs - 1u) & 0xfffffu;
     // (no result copy: the reduction kernel has written the pinned slot itself)
     if (!p->slot_ev[slot]) GPMC_HIP(hipEventCreateWithFlags(&p->slot_ev[slot], hipEventDisableTiming));
     GPMC_HIP(hipEventRecord(p->slot_ev[slot], p->stream));
@@ -669,11 +678,28 @@ int gpmc_plan_result(gpmc_plan* p, int slot, double* out_host) {
     GPMC_ARG(p != nullptr, 1);
     GPMC_ARG(slot >= 0 && slot < PLAN_SLOTS, 2);
     GPMC_ARG(out_host != nullptr, 3);
+    const double* hbase = reinterpret_cast<const double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes);
     if (p->slot_busy[slot]) {                        // wait for THIS slot's evaluation only: later ones keep running
-        GPMC_HIP(hipEventSynchronize(p->slot_ev[slot]));
+        // the reduction writes the execution's number behind the results as its last store: poll that word for a while (a
+        // chain reads every result before it can go on, and the event path costs several microseconds after the kernel has
+        // ended), then fall back to the event
+        const volatile double* stamp = hbase + 4 * PLAN_SLOTS + slot;
+        const double want = (double)p->slot_exec[slot];
+        bool seen = false;
+        if (g_opt.result_poll_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; ++it) {
+                if (*stamp == want) { seen = true; break; }
+                if ((it & 63u) == 63u &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > g_opt.result_poll_us)
+                    break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) GPMC_HIP(hipEventSynchronize(p->slot_ev[slot]));
         p->slot_busy[slot] = 0;
     }
-    const double* hres = reinterpret_cast<const double*>(reinterpret_cast<char*>(p->host_pin) + PLAN_SLOTS * p->hyp_slot_bytes) + 4 * slot;
+    const double* hres = hbase + 4 * slot;
     for (int i = 0; i < 4; ++i) out_host[i] = hres[i];
     if (out_host[3] == (double)GPMC_RING_OUT_OF_STEP) {
         p->resync = true;

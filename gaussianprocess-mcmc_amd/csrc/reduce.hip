@@ -46,7 +46,13 @@ logdet_quad_kernel(const T* __restrict__ W, int n, int ldw, const T* __restrict_
             if (seq && (unsigned)blk[1] != (k & 0xfffffu)) out[3] = (double)GPMC_RING_OUT_OF_STEP;
             for (int j = 0; j < 4; ++j) h[j] = out[j];
             __threadfence_system();
-            if (seq) *seq = k + 1u;
+            if (seq) {
+                *seq = k + 1u;
+                // the execution's number behind its result slot, written last: the host may poll this word instead of
+                // waiting on an event (gpmc_plan_result)
+                host_base[4 * 64 + (int)blk[0]] = (double)(k & 0xfffffu);
+                __threadfence_system();
+            }
         }
     }
 }

@@ -4,7 +4,10 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gaussianprocess-mcmc_amd'))
+import gpmc
 from gpmc import core
+for kv in sys.argv[2:]:
+    gpmc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 hyps = [[1.0, 10.0, 1.2], [2.0, 8.0, 1.0], [1.5, 9.0, 1.1]]
 for n in [int(v) for v in sys.argv[1].split(',')]:
     rng = np.random.RandomState(124)
