@@ -7,14 +7,8 @@ nshow = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# an evaluation starts at the first K build after a reduction (a plan may split its K build in two launches)
-idx, seen_end = [], True
-for i, r in enumerate(rows):
-    if 'kbuild' in r['Kernel_Name'] and seen_end:
-        idx.append(i)
-        seen_end = False
-    if 'logdet' in r['Kernel_Name']:
-        seen_end = True
+# an evaluation ends with its reduction (a plan may split its K build in two launches, or have none: tile generator)
+idx = [0] + [i + 1 for i, r in enumerate(rows) if 'logdet' in r['Kernel_Name'] and i + 1 < len(rows)]
 segs = [rows[a:b] for a, b in zip(idx, idx[1:] + [len(rows)])]
 def name(r):
     k = r['Kernel_Name']
