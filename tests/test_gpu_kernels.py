@@ -485,6 +485,34 @@ def test_plan_input_dimension_limits(gp):
         gp['core'].LogMarginalPlan(rng.uniform(0, 3, (n, 63)), g, 'matern52ard')
 
 
+def test_parameter_ring_order_and_result_wait_modes(gp):
+    """A plan's parameters travel through a ring of 64 blocks in pinned memory that the evaluation's kernels read by
+    sequence number (no copy launch), and gpmc_plan_result polls the result's stamp before it falls back to the event:
+    150 evaluations with distinct parameters, eight in flight at a time (more executions than ring blocks), return the values
+    the same parameters give one at a time with the event-only wait, bit for bit."""
+    gpmc = gp['gpmc']
+    n = 700
+    x, g = _x(n, 2, 41), np.random.RandomState(42).standard_normal(n) * 5.
+    rng = np.random.RandomState(43)
+    hyps = [[float(a), float(b), float(c)] for a, b, c in zip(rng.uniform(0.5, 3, 150), rng.uniform(5, 15, 150), rng.uniform(0.8, 2, 150))]
+    plan = gp['core'].LogMarginalPlan(x, g, 'rbf')
+    try:
+        gpmc.set_option('result_poll_us', 0)
+        one = [plan(h) for h in hyps]
+    finally:
+        gpmc.set_option('result_poll_us', 20000)
+    got = [None] * len(hyps)
+    depth = 8
+    for i, h in enumerate(hyps):
+        if i >= depth:
+            got[i - depth] = plan.result((i - depth) % depth)[0]
+        plan.eval_async(h, i % depth)
+    for i in range(len(hyps) - depth, len(hyps)):
+        got[i] = plan.result(i % depth)[0]
+    assert got == one
+    plan.close()
+
+
 # ---------------------------------------------------------------------------------- plan lifecycle (round 2)
 def _churn(gp, plan, form, devsync, iters):
     from gpmc import _lib
