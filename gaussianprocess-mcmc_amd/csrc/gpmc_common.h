@@ -216,6 +216,9 @@ template <typename T>
 int veccopy(T* dst, const T* src, int n, hipStream_t s);
 template <typename T>
 int publish_host(const double* out4, const int* info2, const T* vec, int n, double* host_mapped, hipStream_t s);
+template <typename T>
+int shift_diag_sub(T* R, int ldr, int n, const T* shift_dev, T jitter, T* diag_out, const T* f, const T* m, T* row_out,
+                   hipStream_t s);
 // a caller's launch sequence (library launches and the caller's own kernels on one stream) recorded and replayed:
 // gpmc_seq_* in plan.hip; retirement follows the same rule as the plans' execs (graveyard on runtimes < 7.2)
 struct Seq {

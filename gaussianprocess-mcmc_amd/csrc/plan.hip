@@ -369,6 +369,14 @@ int gpmc_potrf_tri_f32(float* W, int mp, int np_, int ldw, int ntri, int* info_d
 }
 int gpmc_veccopy_f64(double* dst, const double* src, int n, gpmc_stream_t stream) { return veccopy<double>(dst, src, n, S_(stream)); }
 int gpmc_veccopy_f32(float* dst, const float* src, int n, gpmc_stream_t stream) { return veccopy<float>(dst, src, n, S_(stream)); }
+int gpmc_shift_diag_sub_f64(double* R, int ldr, int n, const double* shift_dev, double jitter, double* diag_out, const double* f,
+                            const double* m, double* row_out, gpmc_stream_t stream) {
+    return shift_diag_sub<double>(R, ldr, n, shift_dev, jitter, diag_out, f, m, row_out, S_(stream));
+}
+int gpmc_shift_diag_sub_f32(float* R, int ldr, int n, const float* shift_dev, float jitter, float* diag_out, const float* f,
+                            const float* m, float* row_out, gpmc_stream_t stream) {
+    return shift_diag_sub<float>(R, ldr, n, shift_dev, jitter, diag_out, f, m, row_out, S_(stream));
+}
 int gpmc_publish_host_f64(const double* out4, const int* info2, const double* vec, int n, double* host_mapped, gpmc_stream_t stream) {
     return publish_host<double>(out4, info2, vec, n, host_mapped, S_(stream));
 }

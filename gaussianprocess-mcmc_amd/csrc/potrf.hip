@@ -676,10 +676,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     const int la_pad = (np_ >= 8192) ? 0 : 16000;
     const int pad_serial = (g_opt.gemm_lds_pad < 0) ? 0 : g_opt.gemm_lds_pad;
     const int pad_la = (g_opt.gemm_lds_pad < 0) ? la_pad : g_opt.gemm_lds_pad;
-    if (!(sc && sc->info_cleared)) {
-        int rcz = zero_words(nullptr, 0, info_dev, s);
-        if (rcz) return rcz;
-    }
+    // *info is cleared on s in front of the first launch that can write it: together with the sync words where a fill launch
+    // for those follows on s anyway (one launch instead of two), else by a launch of its own (flush_info)
+    bool info_pending = !(sc && sc->info_cleared);
+    auto flush_info = [&]() -> int {
+        if (!info_pending) return 0;
+        info_pending = false;
+        return zero_words(nullptr, 0, info_dev, s);
+    };
 
     // the last columns as one tile-DAG launch (tail.h): f64
     // (float storage: the kernel converts on load / store, its arithmetic is f64 as in the panel kernels; the f32 trailing
@@ -707,7 +711,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         if ((sync_next + words) * sizeof(unsigned) > TAIL_SYNC_BYTES) return fail(-1, "potrf: sync region overflow");
         unsigned* sync = dag_sync + sync_next;
         if (!sync_zeroed) {     // (sync_next is 0 here: an aligned start; the scratch reserve has 64 bytes of slack for the round-up)
-            int rcz = zero_words(sync, (words * sizeof(unsigned) + 15) & ~(size_t)15, nullptr, st);
+            int* const info_too = (st == s && info_pending) ? info_dev : nullptr;
+            if (info_too) info_pending = false;
+            int rcz = zero_words(sync, (words * sizeof(unsigned) + 15) & ~(size_t)15, info_too, st);
             if (rcz) return rcz;
         }
         sync_next += words;
@@ -802,7 +808,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         for (int k0 = kstart; k0 < np_; k0 += nbs) {
             if (use_tail(k0)) return tail_from(k0);
             const int nbk = (np_ - k0 < nbs) ? np_ - k0 : nbs;
-            int rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s, pk, lpark21, false);
+            int rc = flush_info();
+            if (rc) return rc;
+            rc = factor_panel<T>(W, ldw, k0, nbk, mp_at(k0 + nbk), info_dev, dinv + (size_t)(k0 / NB_IN) * 1024, lpark, s, pk, lpark21, false);
             if (rc) return rc;
             const int k1 = k0 + nbk;
             if (k1 < np_) {
@@ -900,10 +908,14 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
                 int rcb = build_cols(0, nbk, zb ? dag_sync : nullptr, zb);
                 if (rcb) return rcb;
             } else if (fits) {
-                int rcz = zero_words(dag_sync, zb, nullptr, s);
+                int* const info_too = info_pending ? info_dev : nullptr;
+                info_pending = false;
+                int rcz = zero_words(dag_sync, zb, info_too, s);
                 if (rcz) return rcz;
             }
             sync_zeroed = fits;
+            int rci = flush_info();
+            if (rci) return rci;
         }
         {
             hipEvent_t ef;
@@ -982,7 +994,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
         hipEvent_t pe_prev, ge_prev = nullptr;
         {
             hipEvent_t ef;   // fork: the panel stream starts behind whatever built the matrix on s
-            int rc = sc->edge_record(s, &ef);
+            int rc = flush_info();
+            if (rc) return rc;
+            rc = sc->edge_record(s, &ef);
             if (rc) return rc;
             rc = sc->edge_wait(ps, ef);
             if (rc) return rc;
@@ -1040,7 +1054,9 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     int nbk = la_nb(np_);
     if (nbk > np_) nbk = np_;
     {
-        int rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, s, pk, lpark21, false);
+        int rc = flush_info();
+        if (rc) return rc;
+        rc = factor_panel<T>(W, ldw, 0, nbk, mp_at(nbk), info_dev, dinv, lpark, s, pk, lpark21, false);
         if (rc) return rc;
     }
     for (int k0 = 0, nb_next = 0; k0 < np_; k0 += nbk, nbk = nb_next) {

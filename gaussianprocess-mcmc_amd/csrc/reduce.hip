@@ -172,6 +172,36 @@ int publish_host(const double* out4, const int* info2, const T* vec, int n, doub
 template int publish_host<double>(const double*, const int*, const double*, int, double*, hipStream_t);
 template int publish_host<float>(const double*, const int*, const float*, int, double*, hipStream_t);
 
+// The SDS proposal's small steps between R = -P P^T (gpmc_syrk_tri2) and chol(R + 1e-11 I) in ONE launch (they were four
+// elementwise launches of ~5 us each, a fifth of a proposal at the reference's demo sizes): diag(R) += *shift_dev (the s of
+// s I - P P^T, read on the device), diag_out = that diagonal (the jitter schedule's yardstick and what restores R), diag(R) +=
+// jitter (the 1e-11 of sliceSample.py:205), and the riding row row_out = f - m (sliceSample.py:206).  The same additions in
+// the same order as the launches it replaces: the same bits.
+template <typename T>
+__global__ void __launch_bounds__(256)
+shift_diag_sub_kernel(T* __restrict__ R, int ldr, int n, const T* __restrict__ shift_dev, T jitter, T* __restrict__ diag_out,
+                      const T* __restrict__ f, const T* __restrict__ m, T* __restrict__ row_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    T d = R[(size_t)i * ldr + i] + shift_dev[0];
+    diag_out[i] = d;
+    R[(size_t)i * ldr + i] = d + jitter;
+    row_out[i] = f[i] - m[i];
+}
+template <typename T>
+int shift_diag_sub(T* R, int ldr, int n, const T* shift_dev, T jitter, T* diag_out, const T* f, const T* m, T* row_out,
+                   hipStream_t s) {
+    GPMC_ARG(R != nullptr && n > 0 && ldr >= n, 1);
+    GPMC_ARG(shift_dev != nullptr && diag_out != nullptr, 4);
+    GPMC_ARG(f != nullptr && m != nullptr && row_out != nullptr, 7);
+    hipLaunchKernelGGL((shift_diag_sub_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, R, ldr, n, shift_dev, jitter,
+                       diag_out, f, m, row_out);
+    GPMC_LAUNCH_CHECK();
+    return 0;
+}
+template int shift_diag_sub<double>(double*, int, int, const double*, double, double*, const double*, const double*, double*, hipStream_t);
+template int shift_diag_sub<float>(float*, int, int, const float*, float, float*, const float*, const float*, float*, hipStream_t);
+
 template <typename T>
 int pack_lower(const T* A, int n, int lda, T jitter, T* W, int np_, int ldw, hipStream_t s) {
     GPMC_ARG(A && n > 0 && lda >= n, 1);

@@ -64,6 +64,8 @@ def _sig(lib):
         'gpmc_potrf_tri_f32': ([P, I, I, I, I, P, P, P], I),
         'gpmc_reset_tri_f64': ([P, I, I, P, P], I), 'gpmc_reset_tri_f32': ([P, I, I, P, P], I),
         'gpmc_veccopy_f64': ([P, P, I, P], I), 'gpmc_veccopy_f32': ([P, P, I, P], I),
+        'gpmc_shift_diag_sub_f64': ([P, I, I, P, c_double, P, P, P, P, P], I),
+        'gpmc_shift_diag_sub_f32': ([P, I, I, P, c_float, P, P, P, P, P], I),
         'gpmc_publish_host_f64': ([P, P, P, I, P, P], I), 'gpmc_publish_host_f32': ([P, P, P, I, P, P], I),
         'gpmc_seq_begin': ([ctypes.POINTER(c_void_p), P], I), 'gpmc_seq_end': ([P], I),
         'gpmc_seq_launch': ([P, P], I), 'gpmc_seq_retire': ([P], I),

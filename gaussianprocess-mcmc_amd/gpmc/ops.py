@@ -101,6 +101,12 @@ def veccopy(dst, src, n):
     check(_fn('veccopy', dst.dtype)(dst.data_ptr(), src.data_ptr(), n, stream_ptr()), 'gpmc_veccopy')
 
 
+def shift_diag_sub(R, n, shift_dev, jitter, diag_out, f, m, row_out):
+    """diag(R) += shift_dev[0]; diag_out = diag(R); diag(R) += jitter; row_out = f - m -- one launch (SDS proposal)"""
+    check(_fn('shift_diag_sub', R.dtype)(R.data_ptr(), R.stride(0), n, shift_dev.data_ptr(), float(jitter), diag_out.data_ptr(),
+                                         f.data_ptr(), m.data_ptr(), row_out.data_ptr(), stream_ptr()), 'gpmc_shift_diag_sub')
+
+
 def publish_host(out4, info2, vec, n, host_pinned):
     """out4, *info2 and vec[0:n] into pinned host memory (float64 tensor of >= 8 + n, device-mapped): no copy node"""
     check(_fn('publish_host', vec.dtype)(out4.data_ptr(), info2.data_ptr(), vec.data_ptr(), n, host_pinned.data_ptr(),

@@ -32,6 +32,7 @@ import torch
 
 from . import _lib, covK, ops
 
+RECORD_MIN_NP = 6144      # SDSWorkspace.proposal records its launch sequence from this many padded columns on
 R_JITTER = 1e-11          # sliceSample.py:205
 
 
@@ -167,6 +168,24 @@ class SDSWorkspace(object):
             ops.symv_lower(self.WR, n, self.gs, self.m)
         self.Rdiag.copy_(self.WR.diagonal()[:n])
 
+    def _make_chol_R(self):
+        """the happy path of ``_make_R`` + ``_chol_R(0.0)``: in the inverse form the steps between the SYRK and the
+        factorisation -- shift the diagonal by s_A, save it, add the 1e-11, write f - m into the riding row -- are ONE launch
+        (``gpmc_shift_diag_sub``: they were four elementwise launches, ~25 us of a 0.4 ms proposal at N = 455); the same
+        additions in the same order, the same bits"""
+        if self.form != 'inv':
+            self._make_R()
+            self._chol_R(0.0)
+            return
+        n, np_ = self.n, self.np_
+        rows = self.WA[self.rows0:self.rows0 + np_]
+        ops.syrk_tri(rows, self.WR, n, np_, 0.0, C2=self.R0)      # -P P^T (identity on the padding), kept twice
+        ops.trmv_upper(rows, n, self.WA[self.g_row], self.g_in, -1.0, self.m)
+        if self._sA != self.Sii:
+            self.m.mul_(self._sA / self.Sii)
+        ops.shift_diag_sub(self.WR, n, self.kpS[1:2], R_JITTER, self.Rdiag, self.f_in, self.m, self.WR[np_, :n])
+        ops.potrf(self.WR, self.mpR, np_, self.infoR, self.scratchR, rhs_rows=1)
+
     def _chol_R(self, jitter):
         """C = chol(R + (1e-11 + jitter) I) in place, eta = C^-1 (f - m) riding"""
         n, np_ = self.n, self.np_
@@ -202,8 +221,7 @@ class SDSWorkspace(object):
         self._retried = False
         self._set_hyp(hyp)
         self._factor_A(0.0)
-        self._make_R()
-        self._chol_R(0.0)
+        self._make_chol_R()
         self._results()
         return self._finish(maxtries)
 
@@ -216,8 +234,7 @@ class SDSWorkspace(object):
             jitter = diag_mean * 1e-9
             for _ in range(maxtries):
                 self._factor_A(jitter)
-                self._make_R()
-                self._chol_R(0.0)
+                self._make_chol_R()
                 self._results()
                 G, infoA, infoR = self._read()
                 if infoA == 0:
@@ -265,8 +282,7 @@ class SDSWorkspace(object):
         s I riding -> L', alpha', P' -> G'; R' = s I - P' P'^T, m'; chol(R' + 1e-11 I) with f - m' riding; f' = C' eta + m';
         results and f' to pinned host memory"""
         self._factor_A(0.0)
-        self._make_R()
-        self._chol_R(0.0)
+        self._make_chol_R()
         ops.trmv_lower(self.WR, self.n, self.ita_in, self.m, self.prop_f)
         self._results()
 
@@ -304,11 +320,16 @@ class SDSWorkspace(object):
         except Exception:
             pass
 
-    def proposal(self, hyp, maxtries=5, record=True):
+    def proposal(self, hyp, maxtries=5, record=None):
         """(G', f') for proposed hyper-parameters: the reference's loop body sliceSample.py:136-147 (K build, aux_var_model
-        with the iteration's g, prop_f, propG).  The first proposal of a workspace launches eagerly, the second records
-        the sequence, later ones replay it: ONE stream synchronisation per proposal.  If a factorisation fails the
-        jitter schedules run eagerly, exactly as in ``aux_var_model``."""
+        with the iteration's g, prop_f, propG).  ONE stream synchronisation per proposal either way; ``record`` (None =
+        by size): the first proposal of a workspace launches eagerly, the second records the sequence, later ones
+        replay it -- which pays from about 6000 padded columns on (N = 8192: 15.76 vs 15.80 ms) and costs below that: a
+        graph launch reaches its first kernel 20-30 us later than the first of ~30 eager launches does, 6 % of a proposal
+        at the reference's demo sizes (N = 455: 0.410 vs 0.386 ms, 1024: 0.711 vs 0.690, 2048: 1.354 vs 1.325).  If a
+        factorisation fails the jitter schedules run eagerly, exactly as in ``aux_var_model``."""
+        if record is None:
+            record = self.np_ >= RECORD_MIN_NP
         if os.environ.get('GPMC_SDS_RECORD') == '0':     # development: eager launches
             record = False
         self._set_hyp(hyp)

@@ -95,6 +95,12 @@ int gpmc_potrf_rhs_f32(float* W, int mp, int np_, int ldw, int ntri, int rhs_row
  * device-mapped host memory: host[0..3] = out4, host[4] = *info2, host[8 .. 8 + n) = vec (as doubles). */
 int gpmc_veccopy_f64(double* dst, const double* src, int n, gpmc_stream_t stream);
 int gpmc_veccopy_f32(float* dst, const float* src, int n, gpmc_stream_t stream);
+/* between R = -P P^T (gpmc_syrk_tri2) and chol(R + 1e-11 I) of an SDS proposal, one launch: diag(R) += *shift_dev (the s of
+ * s I - P P^T), diag_out = that diagonal, diag(R) += jitter (the 1e-11 of sliceSample.py:205), row_out = f - m (:206) */
+int gpmc_shift_diag_sub_f64(double* R, int ldr, int n, const double* shift_dev, double jitter, double* diag_out, const double* f,
+                            const double* m, double* row_out, gpmc_stream_t stream);
+int gpmc_shift_diag_sub_f32(float* R, int ldr, int n, const float* shift_dev, float jitter, float* diag_out, const float* f,
+                            const float* m, float* row_out, gpmc_stream_t stream);
 int gpmc_publish_host_f64(const double* out4, const int* info2, const double* vec, int n, double* host_mapped, gpmc_stream_t stream);
 int gpmc_publish_host_f32(const double* out4, const int* info2, const float* vec, int n, double* host_mapped, gpmc_stream_t stream);
 /* A caller's launch sequence -- library launches and the caller's own kernels, all on `stream` (the look-ahead's second

@@ -399,7 +399,7 @@ def test_recorded_proposal_sequence_matches_eager(gp, n):
     ws.aux_var_model(f, pts[0], g, need_eta=True)
     ita = ws.eta.clone()
     ws.begin(f, g, ita)
-    got = [ws.proposal(p) for p in pts]
+    got = [ws.proposal(p, record=True) for p in pts]
     assert ws._seq is not None
     for p, (G, fp) in zip(pts, got):
         Gr = ws2.aux_var_model(f, p, g, need_eta=False)
@@ -450,7 +450,7 @@ def test_R_jitter_schedule_restores_R_from_its_second_copy(gp, hyp, min_steps):
     ita = ws.eta.clone()
     ws.begin(f, g, ita)
     for pt in ([1.0, 10.0, 1.2], hyp, [1.3, 9.0, 1.1], hyp, hyp):
-        Gp, fp = ws.proposal(pt)
+        Gp, fp = ws.proposal(pt, record=True)
         assert ws._retried == (pt is hyp)
         Gr = ws2.aux_var_model(f, pt, g, need_eta=False)
         assert Gp == Gr and np.array_equal(fp, ws2.propose_f(ita).cpu().numpy())
