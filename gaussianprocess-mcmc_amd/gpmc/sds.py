@@ -77,9 +77,12 @@ class SDSWorkspace(object):
         self.scratchR = ops.potrf_scratch(np_, dev)
         self.out = torch.zeros(4, dtype=torch.float64, device=dev)
         nk = 2 + (1 if kernel == 'rbf' else self.d)
-        self.kp_dev = torch.zeros(2 * nk, dtype=dtype, device=dev)      # [kpS | kp0], staged by ONE copy from pinned memory
+        # [kpS | kp0] in pinned host memory, read by the kernels THROUGH ITS DEVICE MAPPING (same address on ROCm): no copy per
+        # proposal -- the copy was a 3 us blit plus ~17 us before the next kernel could start (profiles/r03_sds_timeline_*),
+        # 5 % of a proposal at N = 455.  The K build stages the values in LDS once per workgroup; the other readers take one
+        # scalar load per wave.  The host rewrites the block only between proposals, every one of which ends synchronised.
         self.kp_host = torch.zeros(2 * nk, dtype=dtype).pin_memory()
-        self.kpS, self.kp0 = self.kp_dev[:nk], self.kp_dev[nk:]
+        self.kpS, self.kp0 = self.kp_host[:nk], self.kp_host[nk:]
         self.m = torch.zeros(n, dtype=dtype, device=dev)
         self.gs = torch.zeros(n, dtype=dtype, device=dev)
         self.prop_f = torch.zeros(n, dtype=dtype, device=dev)
@@ -115,7 +118,6 @@ class SDSWorkspace(object):
         nk = kp.shape[0]
         self.kp_host[:nk] = torch.as_tensor(kp, dtype=self.dtype)
         self.kp_host[nk:] = torch.as_tensor(kp0, dtype=self.dtype)
-        self.kp_dev.copy_(self.kp_host, non_blocking=True)       # one H2D from pinned memory, ordered on the current stream
 
     def _factor_A(self, jitter):
         """K + S (+ jitter) with g and either s I ('inv') or K ('syrk') riding: L, alpha = L^-1 g and P = s L^-T or
