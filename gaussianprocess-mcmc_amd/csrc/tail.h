@@ -34,8 +34,9 @@
 //   sc1 loads, s_sleep between polls), pass a workgroup barrier and read the tile with sc1 loads -- the "8-byte agent
 //   atomics on both sides" form of the CDNA4 guide (MI355X_MICROARCH.md, inter-workgroup visibility, row 1 of the
 //   measured hand-off table).  flag[c][i] = 1 once tile (i,c) is in W.  The flags are polled from the first
-//   instruction on, so they are zeroed by a memset node: every launch of a factorisation has its own sync region and
-//   ONE memset in front of the whole factorisation zeroes them all (a memset in front of each launch delays it by
+//   instruction on, so they are zeroed before the launch: every launch of a factorisation has its own sync region and
+//   ONE fill in front of the whole factorisation zeroes them all -- a kernel (zero_words: replayed memset nodes are not
+//   safe on HIP 7.0), or, for a log-marginal plan, the K build's own launch (a fill in front of each launch delays it by
 //   5-10 us, enough for a concurrently launched GEMM to take every CU slot first).
 // * Two MFMA shapes.  The pivot chain (64 x 64 factor, TRSM, the pair's diagonal update) runs on v_mfma_f64_4x4x4; the
 //   off-diagonal accumulation -- the bulk of a large launch -- on v_mfma_f64_16x16x4 (template parameter ACC16 = 4),
