@@ -76,6 +76,8 @@ struct Options {
                               // 8192 4.270 / 4.269 (its tail launch carries 8 history columns), <= 4096 +-0; in the look-ahead
                               // panels (8 columns, 32 workers per queue) beside the GEMM +0.8 %.  Off: nothing for the headline.
     int result_poll_us = 20000;   // gpmc_plan_result polls the result's stamp in pinned memory for up to this long before it waits on the event (0: event only)
+    int tail_whole_m_tri = -1;   // tail_whole_m for factorisations with trapezoidal riding rows; -1 = tail_whole_m
+    int tail_m_tri = 3072;    // tail_m for factorisations with trapezoidal riding rows (gpmc_potrf_tri; 0 = tail_m): the riding trapezoid keeps the look-ahead GEMMs big, so the hand-over to the tile-DAG launch pays later (SDS proposal at N = 8192: 15.74 ms at 6144, 15.10 at 4096, 15.04 at 3072, 14.99 at 2048; N = 12288: 47.9 / 46.9 / 47.7 at 6144 / 3072 / 2048)
     int kbuild_split = 1;     // a plan builds the first look-ahead panel's columns first and the rest of K beside that panel's factorisation
     int tail_park = 1;        // tile-DAG workers step aside while a pair on their CU is inside its critical window (tail.h)
     int tail_workers = 0;     // worker workgroups of a tile-DAG launch that has the chip to itself (plus one per tile column);

@@ -251,6 +251,8 @@ int gpmc_set_option(const char* name, int value) {
     else if (!strcmp(name, "tail_workers")) g_opt.tail_workers = value < 0 ? 0 : value;   // 0 = auto (potrf.hip, alone_workers)
     else if (!strcmp(name, "tail_park")) g_opt.tail_park = value ? 1 : 0;
     else if (!strcmp(name, "kbuild_split")) g_opt.kbuild_split = value ? 1 : 0;
+    else if (!strcmp(name, "tail_whole_m_tri")) { if (value < -1 || (value > 0 && value % 128)) return fail(-2, "tail_whole_m_tri must be -1 or a multiple of 128"); g_opt.tail_whole_m_tri = value; }
+    else if (!strcmp(name, "tail_m_tri")) { if (value < 0 || value % 128) return fail(-2, "tail_m_tri must be a multiple of 128"); g_opt.tail_m_tri = value; }
     else if (!strcmp(name, "result_poll_us")) g_opt.result_poll_us = value < 0 ? 0 : value;
     else if (!strcmp(name, "tail_xcd")) g_opt.tail_xcd = value ? 1 : 0;
     else if (!strcmp(name, "tail_skip")) g_opt.tail_skip = value & 3;
@@ -305,6 +307,8 @@ int gpmc_get_option(const char* name) {
     if (!strcmp(name, "tail_workers")) return g_opt.tail_workers;
     if (!strcmp(name, "tail_park")) return g_opt.tail_park;
     if (!strcmp(name, "kbuild_split")) return g_opt.kbuild_split;
+    if (!strcmp(name, "tail_m_tri")) return g_opt.tail_m_tri;
+    if (!strcmp(name, "tail_whole_m_tri")) return g_opt.tail_whole_m_tri;
     if (!strcmp(name, "result_poll_us")) return g_opt.result_poll_us;
     if (!strcmp(name, "tail_xcd")) return g_opt.tail_xcd;
     if (!strcmp(name, "tail_skip")) return g_opt.tail_skip;

@@ -688,8 +688,8 @@ int potrf(T* W, int mp, int np_, int ldw, int* info_dev, void* scratch, hipStrea
     // the last columns as one tile-DAG launch (tail.h): f64
     // (float storage: the kernel converts on load / store, its arithmetic is f64 as in the panel kernels; the f32 trailing
     // GEMM is twice as fast as the f64 one, so the extents where the launch pays are smaller: tail_m_f32, tail_whole_m_f32)
-    const int tail_m_T = sizeof(T) == 8 ? g_opt.tail_m : g_opt.tail_m_f32;
-    const int tail_whole_T = sizeof(T) == 8 ? g_opt.tail_whole_m : g_opt.tail_whole_m_f32;
+    const int tail_m_T = sizeof(T) == 8 ? ((ntri > 0 && g_opt.tail_m_tri > 0) ? g_opt.tail_m_tri : g_opt.tail_m) : g_opt.tail_m_f32;
+    const int tail_whole_T = sizeof(T) == 8 ? ((ntri > 0 && g_opt.tail_whole_m_tri >= 0) ? g_opt.tail_whole_m_tri : g_opt.tail_whole_m) : g_opt.tail_whole_m_f32;
     const bool tail_ok = tail_m_T > 0 && fused && g_opt.panel_impl == 1;
     auto use_tail = [&](int k0) {
         return tail_ok && np_ - k0 <= ((k0 == 0 && tail_whole_T > tail_m_T) ? tail_whole_T : tail_m_T) &&

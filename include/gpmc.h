@@ -285,7 +285,7 @@ int gpmc_profile_read(double* out6);
  * "la_min_m", "la_nb128_m", "la_depth", "la_order", "panel_pair", "panel_prio", "panel_lds_pad", "use_graph",
  * "small_tile_m", "f32_nb", "gemm_lds_pad"; the tile-DAG schedule (round 2) "tail_m" / "tail_whole_m" (columns the
  * one-launch factorisation takes as a tail / whole; "_f32" variants for float storage), "tail_workers", "dag_workers",
- * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "result_poll_us" (gpmc_plan_result polls the result's stamp in pinned memory this long before waiting on the event; default 20000, 0 = event only), "kbuild_split" (a plan builds the first look-ahead panel's columns first and the rest of K beside that panel; default 1), "tail_park", "tail_xcd" (1: worker tickets in eight queues by column, served XCD by XCD; default 0), "tail_skip" (bit 0: skip the unused half of a riding block, bit 1: its idle waves; gpmc_potrf_rhs), "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
+ * "la_dag", "dag_hist", "dag_ahead", "dag_wprio", "result_poll_us" (gpmc_plan_result polls the result's stamp in pinned memory this long before waiting on the event; default 20000, 0 = event only), "tail_m_tri" / "tail_whole_m_tri" (tail_m / tail_whole_m for factorisations with trapezoidal riding rows, gpmc_potrf_tri: default 3072 / -1 = as tail_whole_m), "kbuild_split" (a plan builds the first look-ahead panel's columns first and the rest of K beside that panel; default 1), "tail_park", "tail_xcd" (1: worker tickets in eight queues by column, served XCD by XCD; default 0), "tail_skip" (bit 0: skip the unused half of a riding block, bit 1: its idle waves; gpmc_potrf_rhs), "tail_warm", "tail_roles_by_index" (measurements only), "tail_spin_limit",
  * "tail_acc16" (1: off-diagonal accumulation on v_mfma_f64_16x16x4; 0: the 4x4x4 form, same bits), "tail_prefetch_t" (tail /
  * whole launches of at least this many tile columns prefetch the next column's operands; 0 = never), "dag_prefetch",
  * "replay_form", "graveyard_max", "shared_card" (1: other processes use this card too -- see INTEGRATION.md section 4); alternative kernels

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""ms per SDS proposal, point by point, recorded sequence vs eager launches (development): python3 scripts/sds_time.py [N]"""
+"""ms per SDS proposal, point by point, recorded sequence vs eager launches (development): python3 scripts/sds_time.py [N] [option=value ...]"""
 import os, sys, time
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'gaussianprocess-mcmc_amd')); sys.path.insert(0, R)
+import gpmc
 from gpmc import sds
 import bench
+for kv in [a for a in sys.argv[2:] if '=' in a]:         # options: name=value
+    gpmc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 X, g, pts = bench.synth_inputs(n, 2, threads=16)
 f = torch.zeros(n, dtype=torch.float64, device='cuda'); gd = torch.as_tensor(g).cuda()

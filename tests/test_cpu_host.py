@@ -59,7 +59,7 @@ assert L.gpmc_version() == 100 and L.gpmc_pad(200) == 256 and L.gpmc_pad(8192) =
 assert L.gpmc_potrf_scratch_bytes(8192) > 2 << 20
 assert L.gpmc_plan_workspace_bytes(8192, 2, 8) > 8192 * 8192 * 8 and L.gpmc_plan_workspace_bytes(0, 2, 8) == 0
 for name in (b'outer_nb', b'lookahead', b'tail_m', b'dag_workers', b'tail_workers', b'la_dag', b'replay_form', b'use_graph',
-             b'tail_acc16', b'tail_prefetch_t', b'dag_prefetch', b'tail_m_f32', b'kbuild_split', b'result_poll_us'):
+             b'tail_acc16', b'tail_prefetch_t', b'dag_prefetch', b'tail_m_f32', b'kbuild_split', b'result_poll_us', b'tail_m_tri', b'tail_whole_m_tri'):
     v = L.gpmc_get_option(name); assert L.gpmc_set_option(name, v) == 0 and L.gpmc_get_option(name) == v, name
 assert L.gpmc_get_option(b'tail_workers') == 0      # 0 = auto (worker count by the launch's bulk-to-chain ratio) survives a set
 assert L.gpmc_set_option(b'outer_nb', 100) != 0 and b'multiple of 128' in L.gpmc_last_error()
