@@ -364,6 +364,44 @@ def test_potrf_tri_returns_scaled_inverse_factor(gp, n, dtype):
     assert torch.equal(ops.unpack_lower(W2, np_, n), ops.unpack_lower(W, np_, n))
 
 
+def test_potrf_tri_hand_over_point_does_not_change_the_bits(gp):
+    """tail_m_tri moves the column at which a factorisation with trapezoidal riding rows hands over from the look-ahead
+    (panels + GEMMs, riding rows included) to the tile-DAG launch -- a schedule of the same sums: L, alpha and
+    P = s L^-T identical, bit for bit, at a look-ahead size (7300 -> 7424 padded columns) for the default (3072), the
+    plain factorisation's point (0 = tail_m, 6144) and an early one (2048), and the plain factorisation's L with them."""
+    ops, gpmc = gp['ops'], gp['gpmc']
+    n, s = 7300, 1.7
+    np_ = ops.pad(n)
+    mp = 2 * np_ + ops.PAD
+    rng = np.random.RandomState(3)
+    x = rng.uniform(0, 10, (n, 2))
+    Kd = torch.as_tensor(x).cuda()
+    kp = torch.tensor([100.0, s, 1.2], dtype=torch.float64, device='cuda')
+    g = torch.as_tensor(rng.standard_normal(n)).cuda()
+    got = []
+    try:
+        for m in (3072, 0, 2048):
+            gpmc.set_option('tail_m_tri', m)
+            W = torch.zeros((mp, np_), dtype=torch.float64, device='cuda')
+            ops.kbuild('rbf', Kd, kp, W, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+            W[np_, :n] = g
+            torch.diagonal(W[np_ + ops.PAD:]).fill_(s)
+            info = torch.zeros(1, dtype=torch.int32, device='cuda')
+            ops.potrf_tri(W, mp, np_, np_, info, ops.potrf_scratch(np_, W.device), rhs_rows=1)
+            assert int(info.item()) == 0
+            got.append((ops.unpack_lower(W, np_, n).clone(), W[np_, :n].clone(), W[np_ + ops.PAD:np_ + ops.PAD + n, :n].clone()))
+            del W
+    finally:
+        gpmc.set_option('tail_m_tri', 3072)
+    for L, a, P in got[1:]:
+        assert torch.equal(L, got[0][0]) and torch.equal(a, got[0][1]) and torch.equal(P, got[0][2])
+    W2 = torch.zeros((np_ + ops.PAD, np_), dtype=torch.float64, device='cuda')
+    ops.kbuild('rbf', Kd, kp, W2, np_, np_, ops.KB_LOWER | ops.KB_PAD_IDENTITY)
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.potrf(W2, np_ + ops.PAD, np_, info, ops.potrf_scratch(np_, W2.device))
+    assert torch.equal(ops.unpack_lower(W2, np_, n), got[0][0])
+
+
 @pytest.mark.parametrize('n', [64, 200, 1000, 3300])
 def test_syrk_tri_matches_dense(gp, n):
     """C = d I - P P^T for an upper-trapezoidal P: lower triangle vs NumPy, identity on the padding"""
