@@ -104,6 +104,8 @@ class SDSWorkspace(object):
             float(self.Rdiag.mean())
             self.R0.diagonal()[:n].copy_(self.Rdiag)
             self.WR[:np_].copy_(self.R0)
+            self.WR.diagonal()[:n].add_(0.0)                      # (_chol_R's two: the happy path has them in one launch
+            torch.sub(self.f_in, self.m, out=self.WR[np_, :n])    #  of its own, so a retry would be their first use)
         self._last_stream = None   # the stream the last sequence went to, when it is not the current one
         self._dirty = False        # a failed factorisation of K + S has run: its riding rows may hold NaN anywhere
 

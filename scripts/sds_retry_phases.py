@@ -4,7 +4,10 @@ import os, sys, time
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, 'gaussianprocess-mcmc_amd')); sys.path.insert(0, R)
+import gpmc
 from gpmc import sds
+for kv in [a for a in sys.argv[1:] if '=' in a]:
+    gpmc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 import bench
 n = 8192
 X, g, pts = bench.synth_inputs(n, 2, threads=16)
