@@ -46,6 +46,10 @@ class _NullCtx(object):
 
 class SDSWorkspace(object):
     def __init__(self, x, kernel='rbf', dtype=torch.float64, form='inv'):
+        """``dtype``: float64 is the sampler's arithmetic (the reference's).  A float32 workspace is accepted, but R = S - S
+        (K+S)^-1 S has eigenvalues at rounding level, and at float32 resolution jitchol's schedule (at most 1e-5 of the mean
+        diagonal) cannot make it positive definite at realistic sizes: ``aux_var_model`` then raises LinAlgError exactly as
+        the schedule prescribes.  The fp32 configuration of BASELINE.json is the log-marginal plan (core.LogMarginalPlan)."""
         ops.require_gpu()
         if form not in ('inv', 'syrk'):
             raise ValueError("form must be 'inv' or 'syrk'")

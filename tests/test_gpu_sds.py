@@ -54,6 +54,27 @@ def test_symv_trmv_syrk_units(gp):
     assert np.all(np.diag(full)[n:] == 1.0) and np.all(np.tril(full, -1)[n:, :] == 0.0)
 
 
+@pytest.mark.parametrize('dt', [torch.float64, torch.float32])
+def test_shift_diag_sub_unit(gp, dt):
+    """gpmc_shift_diag_sub == the four elementwise launches it replaces, bit for bit: diag += shift (device scalar), copy of the
+    diagonal out, diag += jitter, row = f - m; nothing else of R is touched"""
+    ops = gp['ops']
+    n, ld = 333, 384
+    rng = np.random.RandomState(9)
+    R = torch.as_tensor(rng.standard_normal((ld + 1, ld))).to(device='cuda', dtype=dt)
+    f = torch.as_tensor(rng.standard_normal(n)).to(R)
+    m = torch.as_tensor(rng.standard_normal(n)).to(R)
+    shift = torch.as_tensor([1.44, 7.0]).to(R)
+    want = R.clone()
+    want.diagonal()[:n].add_(shift[0])
+    dref = want.diagonal()[:n].clone()
+    want.diagonal()[:n].add_(1e-11 if dt == torch.float64 else 1e-6)
+    torch.sub(f, m, out=want[ld, :n])
+    dout = torch.zeros(n, dtype=dt, device='cuda')
+    ops.shift_diag_sub(R, n, shift[0:1], 1e-11 if dt == torch.float64 else 1e-6, dout, f, m, R[ld, :n])
+    assert torch.equal(R, want) and torch.equal(dout, dref)
+
+
 @pytest.mark.parametrize('form', ['inv', 'syrk'])
 @pytest.mark.parametrize('n', [8, 64, 200])
 def test_aux_var_model_device_vs_reference_fixture(golden_dir, gp, n, form):
